@@ -1,0 +1,250 @@
+"""TEST INFRASTRUCTURE ONLY — generates tests/golden/*.npz|json by running the REFERENCE's own classes
+(loaded by oracle/extract_ref.py from /root/reference, build container only) on seeded inputs with the
+deterministic synthetic weights of lightdiffusion_amd/weights.py.
+
+Run:  python oracle/make_golden.py            (≈2-3 min on 8 cores; rewrites every fixture)
+The fixtures hold only inputs that cannot be regenerated from a seed, and expected outputs — never
+reference source.  Weights are *not* stored: they are a pure function of (key name, shape, seed).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lightdiffusion_amd import weights as W          # noqa: E402
+from oracle.extract_ref import load_reference         # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+ref = load_reference()
+torch.set_grad_enabled(False)
+torch.set_num_threads(os.cpu_count())
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print("wrote", name, {k: tuple(np.asarray(v).shape) for k, v in arrs.items()})
+
+
+def fill(module, prefix=""):
+    """Fill every parameter of a reference module from the name-keyed generator (strict)."""
+    sd = module.state_dict()
+    new = {k: W.synth_tensor(prefix + k, tuple(v.shape)) for k, v in sd.items()}
+    module.load_state_dict(new, strict=True)
+    return module
+
+
+def ref_unet_config(cfg):
+    c = dict(use_checkpoint=False, image_size=32, use_spatial_transformer=True, legacy=False, adm_in_channels=None,
+             use_linear_in_transformer=False, use_temporal_resblock=False, use_temporal_attention=False)
+    c.update({k: cfg[k] for k in ("in_channels", "out_channels", "model_channels", "num_res_blocks", "transformer_depth",
+                                  "transformer_depth_output", "channel_mult", "transformer_depth_middle", "context_dim")})
+    return c
+
+
+def build_ref_model(cfg):
+    """sm_SD15 → BaseModel (LD.py:5964, 5798) with fp32 weights, wrapped in a ModelPatcher (LD.py:3210)."""
+    mcfg = ref.sm_SD15(ref_unet_config(cfg))
+    mcfg.unet_config["num_heads"] = cfg["num_heads"]
+    mcfg.set_inference_dtype(torch.float32, None)
+    model = ref.BaseModel(mcfg, model_type=ref.ModelType.EPS, device=None)
+    fill(model.diffusion_model)
+    model.eval()
+    cpu = torch.device("cpu")
+    return model, ref.ModelPatcher(model, load_device=cpu, offload_device=cpu)
+
+
+# ------------------------------------------------------------------ 1. schedules
+def g_schedules():
+    mcfg = ref.sm_SD15(ref_unet_config(W.tiny_unet_config()))
+    ms = ref.model_sampling(mcfg, ref.ModelType.EPS)
+    k20 = ref.calculate_sigmas(ms, "karras", 20)
+    n30 = ref.calculate_sigmas(ms, "normal", 30)
+    # KSampler1.set_steps with denoise 0.45, 10 steps (hires-fix, LD.py:3097-3104, 10592-10603)
+    n10_045 = ref.calculate_sigmas(ms, "normal", int(10 / 0.45))[-11:]
+    probe = torch.cat([k20[:-1], torch.tensor([0.03, 0.5, 1.0, 7.7, 14.6, 20.0])])
+    tq = torch.tensor([0.0, 0.5, 10.25, 500.0, 998.75, 999.0])
+    save("schedules", sigmas=ms.sigmas, log_sigmas=ms.log_sigmas, karras20=k20, normal30=n30, normal10_d045=n10_045,
+         probe_sigma=probe, probe_t=ms.timestep(probe), tq=tq, sigma_of_t=ms.sigma(tq),
+         temb_t=torch.tensor([0.0, 1.0, 37.0, 999.0]),
+         temb=ref.timestep_embedding(torch.tensor([0.0, 1.0, 37.0, 999.0]), 320),
+         anc=np.array([ref.get_ancestral_step(a, b) for a, b in ((14.6, 11.7), (1.0, 0.5), (0.05, 0.0))], dtype=np.float64))
+
+
+# ------------------------------------------------------------------ 2. blocks
+def g_blocks():
+    ops = ref.disable_weight_init
+    emb = rnd((2, 256), 11)
+    # ResBlock1 with and without skip conv
+    for tag, cin, cout in (("res_skip", 64, 128), ("res_id", 64, 64)):
+        m = fill(ref.ResBlock1(cin, 256, 0.0, out_channels=cout, dims=2, operations=ops), f"blk.{tag}.")
+        x = rnd((2, cin, 12, 10), 12)
+        save("block_" + tag, x=x, emb=emb, y=m(x, emb))
+    m = fill(ref.Downsample1(64, True, dims=2, out_channels=64, operations=ops), "blk.down.")
+    x = rnd((2, 64, 12, 10), 13)
+    save("block_down", x=x, y=m(x))
+    m = fill(ref.Upsample1(64, True, dims=2, out_channels=64, operations=ops), "blk.up.")
+    x = rnd((2, 64, 6, 5), 14)
+    save("block_up", x=x, y=m(x, output_shape=(2, 64, 12, 10)), y_odd=m(x, output_shape=(2, 64, 11, 9)))
+    # transformer pieces: C=64, heads=8 (d=8) and C=80, heads=2 (d=40)
+    for tag, c, heads, cd in (("h8d8", 64, 8, 64), ("h2d40", 80, 2, 96)):
+        ctx = rnd((2, 77, cd), 15)
+        m = fill(ref.BasicTransformerBlock(c, heads, c // heads, context_dim=cd, operations=ops), f"blk.tb.{tag}.")
+        x = rnd((2, 48, c), 16)
+        save("block_tb_" + tag, x=x, ctx=ctx, y=m(x.clone(), context=ctx, transformer_options={"block": ("input", 1)}))
+    m = fill(ref.SpatialTransformer(64, 8, 8, depth=1, context_dim=64, operations=ops), "blk.st.")
+    x, ctx = rnd((2, 64, 8, 6), 17), rnd((2, 77, 64), 18)
+    save("block_st", x=x, ctx=ctx, y=m(x, ctx, {"block": ("input", 1)}))
+    q, k, v = rnd((2, 40, 80), 19), rnd((2, 77, 80), 20), rnd((2, 77, 80), 21)
+    save("attention", q=q, k=k, v=v, y_h2=ref.attention_pytorch(q, k, v, 2), y_h10=ref.attention_pytorch(q, k, v, 10))
+    # VAE blocks
+    m = fill(ref.ResnetBlock(in_channels=64, out_channels=32, dropout=0.0), "blk.vres.")
+    x = rnd((1, 64, 10, 12), 22)
+    save("block_vae_res", x=x, y=m(x, None))
+    m = fill(ref.AttnBlock(64), "blk.vattn.")
+    x = rnd((1, 64, 8, 8), 23)
+    save("block_vae_attn", x=x, y=m(x))
+    # GEGLU alone (LD.py:4508-4515)
+    m = fill(ref.GEGLU(64, 256), "blk.geglu.")
+    x = rnd((2, 5, 64), 24)
+    save("block_geglu", x=x, y=m(x))
+
+
+# ------------------------------------------------------------------ 3. UNets
+def g_unets():
+    for tag, cfg, shapes in (("tiny", W.tiny_unet_config(), ((16, 16), (8, 12))), ("sd15", W.sd15_unet_config(), ((64, 64),))):
+        model, _ = build_ref_model(cfg)
+        ms = model.model_sampling
+        for (h, w) in shapes:
+            x = rnd((2, 4, h, w), 31, 3.0)
+            sigma = torch.tensor([2.5, 0.7])
+            ctx = rnd((2, 77, cfg["context_dim"]), 32)
+            t = ms.timestep(sigma).float()
+            xc = ms.calculate_input(sigma, x)
+            eps = model.diffusion_model(xc, t, context=ctx, transformer_options={})
+            den = model.apply_model(x, sigma, c_crossattn=ctx, transformer_options={})
+            save(f"unet_{tag}_{h}x{w}", x=x, sigma=sigma, ctx=ctx, t=t, eps=eps, denoised=den)
+        del model
+
+
+# ------------------------------------------------------------------ 4. sampler trajectories through the reference's own call stack
+def g_samplers():
+    cfg = W.tiny_unet_config()
+    model, patcher = build_ref_model(cfg)
+    pos = [[rnd((1, 77, cfg["context_dim"]), 41), {"pooled_output": None}]]
+    neg = [[rnd((1, 77, cfg["context_dim"]), 42), {"pooled_output": None}]]
+    lat = ref.EmptyLatentImage().generate(128, 96, 1)[0]          # [1,4,12,16]
+    out = {"pos": pos[0][0], "neg": neg[0][0]}
+    # (a) node-level call, Euler-a / normal, txt2img — common_ksampler LD.py:6657; host-generator noise
+    r = ref.common_ksampler(patcher, 1234, 6, 7.5, "euler_ancestral", "normal", pos, neg, lat, denoise=1.0)
+    out["euler_a_txt2img"] = r[0]["samples"]
+    # (b) hires-style img2img: non-zero latent, denoise 0.45
+    lat2 = {"samples": rnd((1, 4, 12, 16), 43, 0.8)}
+    r = ref.common_ksampler(patcher, 77, 4, 8.0, "euler_ancestral", "normal", pos, neg, lat2, denoise=0.45)
+    out["lat2"] = lat2["samples"]
+    out["euler_a_img2img"] = r[0]["samples"]
+    # (c) DPM++ 2M = dpmpp_2m_sde with eta=0 (LD.py:1174) / karras, entered one level lower (`sample`, LD.py:3010)
+    ms = model.model_sampling
+    sig = ref.calculate_sigmas(ms, "karras", 6)
+    noise = ref.prepare_noise(lat["samples"], 99)
+    cpu = torch.device("cpu")
+    # with noise_sampler=None the reference builds a torchsde BrownianTree even when eta=0 (LD.py:1187-1192);
+    # torchsde is absent, so inject a sampler that must never be called on the deterministic path
+    def never(s, sn):
+        raise AssertionError("noise sampler called with eta=0")
+    r = ref.sample(patcher, noise, pos, neg, 7.0, cpu, ref.ksampler("dpmpp_2m_sde", {"eta": 0.0, "noise_sampler": never}), sig,
+                   patcher.model_options, latent_image=lat["samples"], seed=99)
+    out["dpmpp2m_eta0"] = r
+    # (d) DPM++ 2M SDE eta=1 with an injected, seeded noise sampler
+    def mk_ns():
+        g = torch.Generator().manual_seed(5)
+        return lambda s, sn: torch.randn(lat["samples"].shape, generator=g)
+    r = ref.sample(patcher, noise, pos, neg, 7.0, cpu, ref.ksampler("dpmpp_2m_sde", {"eta": 1.0, "noise_sampler": mk_ns()}),
+                   sig, patcher.model_options, latent_image=lat["samples"], seed=99)
+    out["dpmpp2m_sde_injected"] = r
+    # (e) the wrapper hook contract (LD.py:2558-2567): record what the wrapper receives on one call
+    seen = {}
+    def hook(apply_model, params):
+        if not seen:
+            seen.update(input=params["input"].clone(), timestep=params["timestep"].clone(),
+                        ctx=params["c"]["c_crossattn"].clone(), cond_or_uncond=np.array(params["cond_or_uncond"]))
+        return apply_model(params["input"], params["timestep"], **params["c"])
+    p2 = patcher.clone()
+    p2.set_model_unet_function_wrapper(hook)
+    r2 = ref.common_ksampler(p2, 1234, 6, 7.5, "euler_ancestral", "normal", pos, neg, lat, denoise=1.0)
+    assert torch.equal(r2[0]["samples"], out["euler_a_txt2img"])
+    out.update({"hook_" + k: v for k, v in seen.items()})
+    # (f) toy-denoiser trajectories straight through the k-diffusion functions
+    toy = lambda x, s, **kw: x * (1.0 / (1.0 + s.view(-1, 1, 1, 1) ** 2))
+    x0 = rnd((2, 4, 4, 4), 44, 14.0)
+    torch.manual_seed(7)
+    out["toy_euler_a"] = ref.sample_euler_ancestral(toy, x0, ref.get_sigmas_karras(8, 0.03, 14.6), extra_args={})
+    out["toy_dpmpp2m"] = ref.sample_dpmpp_2m_sde(toy, x0, ref.get_sigmas_karras(8, 0.03, 14.6), extra_args={}, eta=0.0,
+                                                 noise_sampler=never)
+    out["toy_dpmpp2m_heun"] = ref.sample_dpmpp_2m_sde(toy, x0, ref.get_sigmas_karras(8, 0.03, 14.6), extra_args={}, eta=0.0,
+                                                      solver_type="heun", noise_sampler=never)
+    out["toy_x0"] = x0
+    save("samplers", **out)
+
+
+# ------------------------------------------------------------------ 5. VAE decoder
+def g_vae():
+    for tag, cfg, hw in (("tiny", W.tiny_vae_config(), (8, 6)), ("sd15", W.sd15_vae_config(), (32, 32))):
+        dec = ref.Decoder(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=cfg["ch"],
+                          ch_mult=cfg["ch_mult"], num_res_blocks=cfg["num_res_blocks"], attn_resolutions=[], dropout=0.0)
+        eng = ref.AutoencodingEngine(None, dec, None)
+        sd = eng.state_dict()
+        eng.load_state_dict({k: W.synth_tensor(k, tuple(v.shape)) for k, v in sd.items()
+                             if not k.startswith("quant_conv")}, strict=False)
+        z = rnd((1, 4) + hw, 51, 1.0 / 0.18215 * 0.2)
+        img = torch.clamp((eng.decode(z) + 1.0) / 2.0, 0.0, 1.0).movedim(1, -1)     # VAE.decode LD.py:6357-6381
+        if tag == "sd15":
+            save("vae_sd15", z=z, img_sub=img[:, ::4, ::4], mean=img.mean(), std=img.std())
+        else:
+            save("vae_tiny", z=z, img=img)
+
+
+# ------------------------------------------------------------------ 6. CLIP + prompt weights
+def g_clip():
+    cfg = W.tiny_clip_config()
+    m = ref.CLIPTextModel(cfg, torch.float32, None, ref.manual_cast)
+    sd = m.state_dict()
+    m.load_state_dict({k: W.synth_tensor(k, tuple(v.shape)) for k, v in sd.items() if k != "text_projection.weight"}, strict=False)
+    g = torch.Generator().manual_seed(61)
+    toks = torch.randint(1000, 40000, (2, 77), generator=g)
+    toks[:, 0] = 49406
+    toks[0, 9:] = 49407
+    toks[1, 30:] = 49407
+    x_last, x_inter, _, pooled = m(toks, None, intermediate_output=-2, final_layer_norm_intermediate=True)
+    save("clip_tiny", tokens=toks, last=x_last, inter_m2=x_inter, pooled=pooled)
+    strs = ["a photo of a cat", "a (red:1.4) car", "((masterpiece)), (best quality:1.2), [x] \\(lit\\)", "(a (b:0.5) c:2)"]
+    tw = {s: ref.token_weights(ref.escape_important(s), 1.0) for s in strs}
+    with open(os.path.join(OUT, "prompt_weights.json"), "w") as f:
+        json.dump(tw, f, indent=1)
+    print("wrote prompt_weights.json")
+
+
+# ------------------------------------------------------------------ 7. bislerp
+def g_bislerp():
+    x = rnd((2, 4, 8, 6), 71)
+    x[0, :, 2, 3] = 0.0
+    x[1, :, 4, 1] = x[1, :, 4, 2]
+    save("bislerp", x=x, y2x=ref.bislerp(x, 12, 16), y_odd=ref.bislerp(x, 9, 11))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["schedules", "blocks", "unets", "samplers", "vae", "clip", "bislerp"]
+    for n in which:
+        globals()["g_" + n]()
