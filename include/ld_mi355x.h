@@ -1,0 +1,127 @@
+/* ld_mi355x.h — C ABI of the MI355X-native SD1.5 denoise hot path (libld_mi355x.so).
+ *
+ * Plain C: opaque handles, raw DEVICE pointers, sizes, a hipStream_t passed as void*.  No torch types.
+ * Every function returns an LD_* status (0 = OK); nothing throws across the boundary.  After `*_reserve`
+ * a handle performs no allocation: `ld_unet_forward` / `ld_vae_decode` only enqueue kernels on the given
+ * stream (safe to capture into a hipGraph: fixed workspace addresses, no host sync, no malloc).
+ *
+ * What each entry point replaces in the reference (file:line into LightDiffusion.py = LD.py):
+ *   ld_unet_forward      BaseModel.apply_model (LD.py:5828-5860) = EPS.calculate_input (1259-1261) →
+ *                        ModelSamplingDiscrete.timestep (1336-1339) → UNetModel1.forward (5688-5767) →
+ *                        EPS.calculate_denoised (1263-1265); i.e. what a `model_function_wrapper`
+ *                        (LD.py:2558-2567, installed by ModelPatcher.set_model_unet_function_wrapper 3277)
+ *                        must return: denoised x0, fp32, same shape as the input.
+ *   ld_unet_set_context  the per-layer to_k / to_v projections of the cross-attention context
+ *                        (CrossAttention.forward LD.py:4028-4036) — step-invariant, so hoisted out of the step.
+ *   ld_vae_decode        VAE.decode (LD.py:6357-6381) = post_quant_conv + Decoder.forward (3470-3473, 3857-3882)
+ *                        + process_output clamp + NCHW→NHWC.
+ *   ld_op_*              single operators, for parity tests: the `operations=` classes of LD.py:2342-2429
+ *                        (Linear / Conv2d / GroupNorm / LayerNorm) and optimized_attention (3966-3988).
+ */
+#ifndef LD_MI355X_H
+#define LD_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LD_OK 0
+#define LD_ERR_ARG 1    /* null / inconsistent argument */
+#define LD_ERR_SHAPE 2  /* shape or alignment not supported by the kernels */
+#define LD_ERR_HIP 3    /* a HIP call or launch failed */
+#define LD_ERR_STATE 4  /* call order (missing weights / reserve / context) */
+
+#define LD_F16 0
+#define LD_F32 1
+
+const char* ld_version(void);
+const char* ld_status_string(int status);
+
+/* ------------------------------------------------------------------ UNet (UNetModel1 ctor arguments, LD.py:5294-5340) */
+typedef struct {
+    int in_channels, out_channels, model_channels;
+    int num_levels;
+    int channel_mult[8];
+    int num_res_blocks[8];
+    int transformer_depth[16];        /* one per input ResBlock */
+    int transformer_depth_output[24]; /* one per output ResBlock, in the reference's (popped-from-the-end) list order */
+    int transformer_depth_middle;
+    int context_dim, num_heads;
+} ld_unet_config;
+
+typedef struct ld_unet ld_unet;
+
+int ld_unet_create(const ld_unet_config* cfg, ld_unet** out);
+void ld_unet_destroy(ld_unet* u);
+/* parameter table: checkpoint key names (minus "model.diffusion_model."), shapes as stored in the checkpoint */
+int ld_unet_param_count(const ld_unet* u);
+int ld_unet_param_info(const ld_unet* u, int index, const char** name, int* ndim, int64_t shape[4]);
+/* copy + repack one checkpoint tensor (device pointer, LD_F16 or LD_F32, checkpoint layout: conv OIHW, linear [out,in]) */
+int ld_unet_load_param(ld_unet* u, const char* name, const void* dev_src, int dtype, void* stream);
+/* size the activation workspace for up to max_n UNet samples (= 2 x image batch under CFG) of max_h x max_w latents */
+int ld_unet_reserve(ld_unet* u, int max_n, int max_h, int max_w, int max_ctx_tokens);
+size_t ld_unet_workspace_bytes(const ld_unet* u);
+size_t ld_unet_weight_bytes(const ld_unet* u);
+/* ctx: [n][tokens][context_dim] (LD_F16 / LD_F32), batch order as the reference builds it: [uncond..., cond...] */
+int ld_unet_set_context(ld_unet* u, const void* ctx, int dtype, int n, int tokens, void* stream);
+/* x, out: [n][in_channels][h][w] fp32 NCHW; sigma: [n] fp32 (sigma, not t).  out = denoised = x - eps * sigma.
+ * eps_only != 0 writes the raw UNet output (fp32 of the fp16 eps) instead. */
+int ld_unet_forward(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, void* stream);
+/* number of kernel launches of the last forward, and algorithmic FLOPs of it (2*M*N*K over every contraction) */
+int ld_unet_last_launches(const ld_unet* u);
+double ld_unet_last_flops(const ld_unet* u);
+
+/* ------------------------------------------------------------------ VAE decoder (Decoder ctor arguments, LD.py:6312-6323) */
+typedef struct {
+    int z_channels, ch, num_levels;
+    int ch_mult[8];
+    int num_res_blocks, out_ch;
+} ld_vae_config;
+
+typedef struct ld_vae ld_vae;
+
+int ld_vae_create(const ld_vae_config* cfg, ld_vae** out);
+void ld_vae_destroy(ld_vae* v);
+int ld_vae_param_count(const ld_vae* v);
+int ld_vae_param_info(const ld_vae* v, int index, const char** name, int* ndim, int64_t shape[4]);
+int ld_vae_load_param(ld_vae* v, const char* name, const void* dev_src, int dtype, void* stream);
+int ld_vae_reserve(ld_vae* v, int max_b, int max_h, int max_w);   /* latent size */
+size_t ld_vae_workspace_bytes(const ld_vae* v);
+/* z: [b][z_channels][h][w] fp32 (already divided by 0.18215); out: [b][8h][8w][3] fp32 in [0,1] */
+int ld_vae_decode(ld_vae* v, const float* z, float* out, int b, int h, int w, void* stream);
+int ld_vae_last_launches(const ld_vae* v);
+double ld_vae_last_flops(const ld_vae* v);
+
+/* ------------------------------------------------------------------ single operators (fp16 device tensors unless noted) */
+/* y[M][N] = act(alpha * x[M][K] · w[N][K]^T + bias[N]) + residual[M][N];  act: 0 none, 1 SiLU, 2 GEGLU (w, bias in
+ * checkpoint row order [value | gate]; y is [M][N/2]).  ws/ws_bytes: optional split-K scratch. */
+int ld_op_linear(const void* x, const void* w, const void* bias, const void* residual, void* y, int M, int N, int K,
+                 float alpha, int act, void* ws, size_t ws_bytes, void* stream);
+/* NHWC conv, ksize 1 or 3 (pad ksize/2), w in [Cout][ky][kx][Cin] order (see ld_op_repack_conv).  Two optional
+ * NHWC sources are concatenated along channels; (hv, wv) != (h, w) resizes the input nearest-neighbour first. */
+int ld_op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int w, int hv, int wv, int stride, int ksize,
+               const void* wt, const void* bias, const void* rowvec, const void* residual, void* y, int cout,
+               void* ws, size_t ws_bytes, void* stream);
+int ld_op_repack_conv(const void* src_oihw, int dtype, int cout, int cin, void* dst, void* stream);
+/* GroupNorm(32) over the channel concat of two NHWC sources (+ optional SiLU); ws >= ld_op_groupnorm_ws_bytes */
+size_t ld_op_groupnorm_ws_bytes(int n, int hw);
+int ld_op_groupnorm(const void* x1, int c1, const void* x2, int c2, int n, int hw, const void* gamma, const void* beta,
+                    float eps, int silu, void* y, void* ws, void* stream);
+int ld_op_layernorm(const void* x, const void* gamma, const void* beta, void* y, int rows, int c, float eps, void* stream);
+/* q [b][lq][heads*d], k [b][lk][heads*d], vt [b][heads*d][lk_pad] (V transposed, lk_pad = ldvt >= lk, multiple of 8) */
+int ld_op_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo, int b,
+                    int heads, int lq, int lk, int d, float scale, void* stream);
+int ld_op_softmax_rows(void* s, int rows, int cols, void* stream);
+int ld_op_timestep_embed(const float* sigma, const float* log_sigmas, int n_sigmas, int n, int dim, void* out_f16, float* t_out,
+                         void* stream);
+/* guidance / sampler elementwise on fp32 latents: out = u + (c-u)*cfg with den2 = [u ; c];  x = a*x + b*y + c*z */
+int ld_op_cfg_combine(const float* den2, float* out, float cfg, size_t n_half, void* stream);
+int ld_op_axpby(float* x, float a, const float* y, float b, const float* z, float c, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LD_MI355X_H */

@@ -1,0 +1,214 @@
+// Flash-style attention for the UNet's self / cross attention (softmax(QK^T/sqrt(d)) V, no mask — LD.py:3966-3978).
+//
+// gfx950 design (32x32x16 f16 MFMA, wave = 64):
+//  * one workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.
+//  * S^T = K·Q^T ("swapped" product): the query sits on the MFMA lane, so a lane's 16 accumulator registers are
+//    16 keys of ONE query and the online softmax needs no cross-lane traffic except one half-wave exchange.
+//  * the S^T accumulator tile is fed straight back as the B operand of O^T += V^T·P^T (cdna guide §3 "accumulator
+//    tile as the next MFMA's operand").  K rows are read through the bit-2<->bit-3 row permutation so that the
+//    permuted k-order of that trick becomes the natural key order and V^T fragments are single 16-byte LDS reads.
+//  * V arrives already transposed ([channel][key], produced by a swapped projection GEMM), so both LDS tiles are
+//    filled with plain 16-byte row copies; rows are padded by 16 B -> conflict-free ds_read_b128.
+//  * K/V tiles (64 keys) are prefetched global->registers under the MFMA phase of the previous tile (T14).
+//  * O rescale is skipped (wave-uniform branch) whenever no running max moved — exact, not thresholded.
+// Head dims: d % 8 == 0, d <= 160 (SD1.5: 40 / 80 / 160).  Template DK = ceil(d/16) k-steps of QK^T.
+#include "kernels.h"
+
+namespace {
+
+constexpr int AT_THREADS = 256;
+constexpr int KT_KEYS = 64;   // keys per LDS tile
+
+template <int DK>
+__global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams p) {
+    constexpr int DV = (DK + 1) / 2;            // 32-row tiles of O^T
+    constexpr int KLD = 16 * DK + 8;            // K tile row stride (halfs)
+    constexpr int VLD = KT_KEYS + 8;            // V^T tile row stride (halfs)
+    constexpr int KCH = KT_KEYS * 2 * DK;       // 16-byte chunks in a (padded-d) K tile
+    constexpr int VCH = 32 * DV * 8;            // chunks in a V^T tile
+    constexpr int KIT = (KCH + AT_THREADS - 1) / AT_THREADS;
+    constexpr int VIT = (VCH + AT_THREADS - 1) / AT_THREADS;
+    __shared__ __attribute__((aligned(16))) half_t Ks[KT_KEYS * KLD];
+    __shared__ __attribute__((aligned(16))) half_t Vs[32 * DV * VLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qblocks = (p.Lq + 127) / 128;
+    const int nblk = qblocks * p.H * p.B;
+    int bid = xcd_remap(blockIdx.x, nblk);
+    const int qb = bid % qblocks;
+    bid /= qblocks;
+    const int head = bid % p.H, b = bid / p.H;
+    const int d = p.d;
+
+    const half_t* Qg = p.Q + (long long)b * p.sQ + head * d;
+    const half_t* Kg = p.K + (long long)b * p.sK + head * d;
+    const half_t* Vg = p.Vt + (long long)b * p.sV + (long long)head * d * p.ldvt;
+
+    // ---- Q fragments (B operand: lane (r,hh) holds Q[q][16*ks + 8*hh .. +7])
+    const int qrow = qb * 128 + wid * 32 + r;
+    half8 qf[DK];
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks) {
+        const int c = 16 * ks + 8 * hh;
+        qf[ks] = as_half8((qrow < p.Lq && c < d) ? ld16(Qg + (long long)qrow * p.ldq + c) : zero16());
+    }
+
+    // ---- zero the LDS tiles once: padded columns/rows are never overwritten by the tile copies
+    for (int i = tid; i < KT_KEYS * KLD / 8; i += AT_THREADS) st16(Ks + i * 8, zero16());
+    for (int i = tid; i < 32 * DV * VLD / 8; i += AT_THREADS) st16(Vs + i * 8, zero16());
+
+    uint4 rk[KIT], rv[VIT];
+    const int dch = d >> 3;   // real 16-byte chunks per key row
+    auto prefetch = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+            const int q = tid + i * AT_THREADS;
+            const int row = q / (2 * DK), cc = q - row * (2 * DK);
+            const bool ok = q < KCH && cc < dch && key0 + row < p.Lk;
+            rk[i] = ok ? ld16(Kg + (long long)(key0 + row) * p.ldk + cc * 8) : zero16();
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            const int q = tid + i * AT_THREADS;
+            const int row = q >> 3, cc = q & 7;
+            const bool ok = q < VCH && row < d && key0 + cc * 8 < p.Lk;   // Lk % 8 == 0 not required: see tail fix below
+            rv[i] = ok ? ld16(Vg + (long long)row * p.ldvt + key0 + cc * 8) : zero16();
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < KIT; ++i) {
+            const int q = tid + i * AT_THREADS;
+            const int row = q / (2 * DK), cc = q - row * (2 * DK);
+            if (q < KCH) st16(Ks + row * KLD + cc * 8, rk[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) {
+            const int q = tid + i * AT_THREADS;
+            const int row = q >> 3, cc = q & 7;
+            if (q < VCH) st16(Vs + row * VLD + cc * 8, rv[i]);
+        }
+    };
+
+    f32x16 o[DV];
+#pragma unroll
+    for (int t = 0; t < DV; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c2 = p.scale * 1.44269504088896340736f;   // scores are exponentiated in base 2
+
+    // permuted K row for this lane's MFMA row r: swap bits 2 and 3
+    const int prow = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+
+    const int ntiles = (p.Lk + KT_KEYS - 1) / KT_KEYS;
+    prefetch(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * KT_KEYS;
+        __syncthreads();   // every wave is done reading the previous tile (and, for t = 0, the zero fill landed)
+        commit();
+        __syncthreads();
+        if (t + 1 < ntiles) prefetch(key0 + KT_KEYS);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (key0 + sub * 32 >= p.Lk) break;   // wave-uniform: nothing valid in this half tile
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) {
+                const half8 kf = as_half8(ld16(Ks + (sub * 32 + prow) * KLD + 16 * ks + 8 * hh));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+            }
+            if (key0 + sub * 32 + 32 > p.Lk) {   // ragged last tile: mask keys >= Lk
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * hh;                       // MFMA row of this register
+                    const int key = (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);         // key it carries
+                    if (key0 + sub * 32 + key >= p.Lk) s[e] = -INFINITY;
+                }
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float mc = m_new * c2;
+            float psum = 0.f;
+            half8 pf[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pe = exp2f(s[e] * c2 - mc);
+                psum += pe;
+                pf[e >> 3][e & 7] = (half_t)pe;
+            }
+            if (__any(m_new > m_run)) {
+                const float alpha = exp2f((m_run - m_new) * c2);
+                l_run *= alpha;
+#pragma unroll
+                for (int tt = 0; tt < DV; ++tt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[tt][e] *= alpha;
+            }
+            l_run += psum;
+            m_run = m_new;
+#pragma unroll
+            for (int tt = 0; tt < DV; ++tt)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const half8 vf = as_half8(ld16(Vs + (tt * 32 + r) * VLD + sub * 32 + 16 * k2 + 8 * hh));
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[k2], o[tt], 0, 0, 0);
+                }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < p.Lq) {
+        half_t* Og = p.O + (long long)b * p.sO + (long long)qrow * p.ldo + head * d;
+#pragma unroll
+        for (int tt = 0; tt < DV; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = tt * 32 + 8 * g + 4 * hh;
+                if (dd < d) {
+                    half4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[tt][4 * g + e] * inv);
+                    *reinterpret_cast<half4*>(Og + dd) = h;
+                }
+            }
+    }
+}
+
+template <int DK>
+void launch_attn(const AttnParams& p, hipStream_t s) {
+    const int nblk = ((p.Lq + 127) / 128) * p.H * p.B;
+    hipLaunchKernelGGL((flash_attn_kernel<DK>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
+}
+
+}  // namespace
+
+int attention_launch(const AttnParams& p, hipStream_t stream) {
+    if (p.Q == nullptr || p.K == nullptr || p.Vt == nullptr || p.O == nullptr) return LD_ERR_ARG;
+    if (p.B <= 0 || p.H <= 0 || p.Lq <= 0 || p.Lk <= 0) return LD_ERR_SHAPE;
+    if (p.d % 8 || p.d <= 0 || p.d > 160) return LD_ERR_SHAPE;
+    // 16-byte row copies: every row start must be 16-byte aligned; V^T rows are read in 8-key chunks, so the
+    // V^T buffer must be allocated (and zero-padded) to a multiple of 8 keys per row
+    if ((p.ldq & 7) || (p.ldk & 7) || (p.ldvt & 7) || (p.ldo & 3) || (p.sQ & 7) || (p.sK & 7) || (p.sV & 7)) return LD_ERR_SHAPE;
+    if (p.ldvt < ((p.Lk + 7) & ~7)) return LD_ERR_SHAPE;
+    const int dk = (p.d + 15) / 16;
+    switch (dk) {
+        case 1: launch_attn<1>(p, stream); break;
+        case 2: launch_attn<2>(p, stream); break;
+        case 3: launch_attn<3>(p, stream); break;
+        case 4: launch_attn<4>(p, stream); break;
+        case 5: launch_attn<5>(p, stream); break;
+        case 6: launch_attn<6>(p, stream); break;
+        case 8: launch_attn<8>(p, stream); break;
+        case 10: launch_attn<10>(p, stream); break;
+        default: return LD_ERR_SHAPE;
+    }
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}

@@ -1,0 +1,131 @@
+// Single-operator entry points of the C ABI (include/ld_mi355x.h) — thin, argument-checked wrappers over the
+// kernel launchers; used by the parity tests and by hosts that want to compose their own graphs.
+#include "kernels.h"
+#include "../../include/ld_mi355x.h"
+
+namespace {
+// scratch for ld_op_linear's GEGLU path: the op takes weights in checkpoint row order, the kernel wants them
+// tile-interleaved, so the op repacks into caller-provided workspace
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+}  // namespace
+
+extern "C" {
+
+const char* ld_version(void) { return "ld_mi355x 0.1 (gfx950)"; }
+
+const char* ld_status_string(int s) {
+    switch (s) {
+        case LD_OK: return "ok";
+        case LD_ERR_ARG: return "invalid argument";
+        case LD_ERR_SHAPE: return "unsupported shape or alignment";
+        case LD_ERR_HIP: return "HIP runtime error";
+        case LD_ERR_STATE: return "invalid call order (weights / reserve / context missing)";
+        default: return "unknown status";
+    }
+}
+
+int ld_op_linear(const void* x, const void* w, const void* bias, const void* residual, void* y, int M, int N, int K, float alpha,
+                 int act, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GemmParams p;
+    p.A = (const half_t*)x; p.lda = K;
+    p.W = (const half_t*)w; p.ldw = K;
+    p.M = M; p.N = N; p.K = K;
+    p.alpha = alpha;
+    p.bias_n = (const half_t*)bias;
+    p.R = (const half_t*)residual;
+    p.act = act;
+    p.C = (half_t*)y;
+    p.ldc = p.ldr = (act == 2 ? N / 2 : N);
+    char* wsp = (char*)ws;
+    if (act == 2) {   // repack [value | gate] rows into the tile-interleaved order the fused epilogue expects
+        if (bias == nullptr || (N & 15)) return LD_ERR_ARG;
+        const int bn = gemm_pick_bn(N);
+        if (N % bn) return LD_ERR_SHAPE;
+        const size_t wb = align256((size_t)N * K * sizeof(half_t)), bb = align256((size_t)N * sizeof(half_t));
+        if (ws == nullptr || ws_bytes < wb + bb) return LD_ERR_ARG;
+        half_t* w2 = (half_t*)wsp;
+        half_t* b2 = (half_t*)(wsp + wb);
+        int st = repack_rows_launch(w, 0, N, K, w2, bn, stream);
+        if (st != LD_OK) return st;
+        st = repack_rows_launch(bias, 0, N, 1, b2, bn, stream);
+        if (st != LD_OK) return st;
+        p.W = w2;
+        p.bias_n = b2;
+        p.bn = bn;
+        wsp += wb + bb;
+        ws_bytes -= wb + bb;
+    }
+    p.partial = (float*)wsp;
+    p.partial_bytes = ws ? ws_bytes : 0;
+    if (ws == nullptr) p.partial = nullptr;
+    return gemm_launch(p, stream);
+}
+
+int ld_op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int w, int hv, int wv, int stride, int ksize,
+               const void* wt, const void* bias, const void* rowvec, const void* residual, void* y, int cout, void* ws,
+               size_t ws_bytes, void* stream) {
+    if (stride < 1 || (ksize != 1 && ksize != 3)) return LD_ERR_ARG;
+    GemmParams p;
+    p.conv = 1;
+    p.ksize = ksize;
+    p.A = (const half_t*)x1; p.A2 = (const half_t*)x2; p.C1 = c1; p.C2 = c2;
+    p.Hs = h; p.Ws = w; p.Hv = hv; p.Wv = wv; p.stride = stride;
+    p.Ho = ksize == 3 ? (hv - 1) / stride + 1 : hv;
+    p.Wo = ksize == 3 ? (wv - 1) / stride + 1 : wv;
+    p.K = ksize * ksize * (c1 + c2);
+    p.W = (const half_t*)wt; p.ldw = p.K;
+    p.M = n * p.Ho * p.Wo; p.N = cout;
+    p.bias_n = (const half_t*)bias;
+    p.rowvec = (const half_t*)rowvec; p.rows_per_vec = p.Ho * p.Wo; p.ldrv = cout;
+    p.R = (const half_t*)residual; p.ldr = cout;
+    p.C = (half_t*)y; p.ldc = cout;
+    p.partial = (float*)ws;
+    p.partial_bytes = ws ? ws_bytes : 0;
+    return gemm_launch(p, (hipStream_t)stream);
+}
+
+int ld_op_repack_conv(const void* src, int dtype, int cout, int cin, void* dst, void* stream) {
+    return repack_conv3x3_launch(src, dtype == LD_F32, cout, cin, (half_t*)dst, (hipStream_t)stream);
+}
+
+size_t ld_op_groupnorm_ws_bytes(int n, int hw) { return groupnorm_workspace_bytes(n, hw); }
+
+int ld_op_groupnorm(const void* x1, int c1, const void* x2, int c2, int n, int hw, const void* gamma, const void* beta, float eps,
+                    int silu, void* y, void* ws, void* stream) {
+    return groupnorm_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, hw, (const half_t*)gamma, (const half_t*)beta, eps,
+                            silu, (half_t*)y, (float*)ws, (hipStream_t)stream);
+}
+
+int ld_op_layernorm(const void* x, const void* gamma, const void* beta, void* y, int rows, int c, float eps, void* stream) {
+    return layernorm_launch((const half_t*)x, (const half_t*)gamma, (const half_t*)beta, (half_t*)y, rows, c, eps, (hipStream_t)stream);
+}
+
+int ld_op_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo, int b, int heads,
+                    int lq, int lk, int d, float scale, void* stream) {
+    AttnParams a;
+    a.Q = (const half_t*)q; a.ldq = ldq; a.sQ = (long long)lq * ldq;
+    a.K = (const half_t*)k; a.ldk = ldk; a.sK = (long long)lk * ldk;
+    a.Vt = (const half_t*)vt; a.ldvt = ldvt; a.sV = (long long)heads * d * ldvt;
+    a.O = (half_t*)o; a.ldo = ldo; a.sO = (long long)lq * ldo;
+    a.B = b; a.H = heads; a.Lq = lq; a.Lk = lk; a.d = d; a.scale = scale;
+    return attention_launch(a, (hipStream_t)stream);
+}
+
+int ld_op_softmax_rows(void* s, int rows, int cols, void* stream) {
+    return softmax_rows_launch((half_t*)s, rows, cols, cols, (hipStream_t)stream);
+}
+
+int ld_op_timestep_embed(const float* sigma, const float* log_sigmas, int n_sigmas, int n, int dim, void* out, float* t_out, void* stream) {
+    return timestep_embed_launch(sigma, log_sigmas, n_sigmas, n, dim, (half_t*)out, t_out, (hipStream_t)stream);
+}
+
+int ld_op_cfg_combine(const float* den2, float* out, float cfg, size_t n_half, void* stream) {
+    return cfg_combine_launch(den2, out, cfg, n_half, (hipStream_t)stream);
+}
+
+int ld_op_axpby(float* x, float a, const float* y, float b, const float* z, float c, size_t n, void* stream) {
+    return axpby_launch(x, a, y, b, z, c, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// Dense contraction C[M,N] = epilogue(alpha * A[M,K] · W[N,K]^T) on MFMA (fp16 in, fp32 accumulate).
+// One kernel family serves nn.Linear, 1x1 conv and — through an implicit-im2col A loader — the 3x3 convs
+// (stride 1/2, fused nearest-upsample, fused channel concat of two NHWC sources).
+#pragma once
+#include "common.h"
+
+struct GemmParams {
+    // ---- A operand (activations, K contiguous)
+    const half_t* A = nullptr;   // plain: [M][lda];  conv: NHWC source 1 [img][Hs][Ws][C1]
+    const half_t* A2 = nullptr;  // conv only: NHWC source 2 [img][Hs][Ws][C2] (virtual channel concat), may be null
+    int lda = 0;
+    int conv = 0;                // 0 plain, 1 implicit im2col conv (ksize x ksize, pad ksize/2)
+    int ksize = 3;               // 1 or 3
+    int Hs = 0, Ws = 0;          // source spatial size
+    int Hv = 0, Wv = 0;          // size the conv sees (after nearest resize; == Hs,Ws without upsample)
+    int Ho = 0, Wo = 0, stride = 1;
+    int C1 = 0, C2 = 0;
+    // ---- B operand (weights [N][K], K contiguous)
+    const half_t* W = nullptr;
+    int ldw = 0;
+    int M = 0, N = 0, K = 0;
+    // ---- batching over blockIdx.z (element strides)
+    int batch = 1;
+    long long sA = 0, sW = 0, sC = 0, sR = 0;
+    // ---- epilogue: v = alpha*acc; v += bias_n[n]; v += bias_m[m]; v += rowvec[m / rows_per_vec][n]; act; v += R[m][n]
+    float alpha = 1.0f;
+    const half_t* bias_n = nullptr;
+    const half_t* bias_m = nullptr;
+    const half_t* rowvec = nullptr;
+    int rows_per_vec = 1, ldrv = 0;
+    const half_t* R = nullptr;
+    int ldr = 0;
+    int act = 0;                 // 0 none, 1 SiLU, 2 GEGLU (weight rows tile-interleaved [BN/2 value | BN/2 gate], out width N/2)
+    half_t* C = nullptr;
+    int ldc = 0;
+    // ---- tiling controls (0 = auto)
+    int bm = 0, bn = 0;          // bn must match the repack-time choice for GEGLU
+    int splitk = 0;
+    float* partial = nullptr;    // split-K workspace, >= splitk*M*N floats
+    size_t partial_bytes = 0;
+};
+
+// BN the GEGLU weight interleave must use for a projection with N (=2*inner) output rows
+static inline int gemm_pick_bn(int N) { return (N % 160 == 0) ? 160 : 128; }
+
+int gemm_launch(const GemmParams& p, hipStream_t stream);

@@ -1,0 +1,71 @@
+// Launcher declarations for the gfx950 kernels (internal to the shared library; the public C ABI is
+// include/ld_mi355x.h).  Every launcher validates shapes on the host and returns an LD_* status.
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+// ---- norm.hip
+static inline int gn_num_chunks(int HW) {
+    int p = (HW + 63) / 64;
+    return p < 1 ? 1 : (p > 256 ? 256 : p);
+}
+size_t groupnorm_workspace_bytes(int n_img, int HW);
+int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, const half_t* gamma,
+                     const half_t* beta, float eps, int silu, half_t* y, float* partial, hipStream_t stream);
+int layernorm_launch(const half_t* x, const half_t* gamma, const half_t* beta, half_t* y, int rows, int C, float eps,
+                     hipStream_t stream);
+int softmax_rows_launch(half_t* s, int rows, int cols, long long ld, hipStream_t stream);
+
+// ---- attention.hip
+struct AttnParams {
+    const half_t* Q = nullptr;   // element (b, l, h, dd) at Q + b*sQ + l*ldq + h*d + dd
+    const half_t* K = nullptr;   // element (b, key, h, dd) at K + b*sK + key*ldk + h*d + dd
+    const half_t* Vt = nullptr;  // element (b, h, dd, key) at Vt + b*sV + (h*d + dd)*ldvt + key   (V transposed)
+    half_t* O = nullptr;         // element (b, l, h, dd) at O + b*sO + l*ldo + h*d + dd
+    int ldq = 0, ldk = 0, ldvt = 0, ldo = 0;
+    long long sQ = 0, sK = 0, sV = 0, sO = 0;
+    int B = 0, H = 0, Lq = 0, Lk = 0, d = 0;
+    float scale = 1.0f;
+};
+int attention_launch(const AttnParams& p, hipStream_t stream);
+
+// ---- misc.hip
+struct SmallConvInArgs {        // 3x3 pad-1 conv with <= 4 input channels from an fp32 NCHW tensor (conv_in of UNet / VAE)
+    const float* x = nullptr;   // [N][Cin][H][W] fp32
+    const float* scale_sigma = nullptr;  // optional [N]: input scaled by 1/sqrt(sigma^2+1) (EPS.calculate_input, LD.py:1259-1261)
+    const half_t* pre_w = nullptr;       // optional 1x1 pre-conv [Cin][Cin] + bias (VAE post_quant_conv, LD.py:3467-3471)
+    const half_t* pre_b = nullptr;
+    const half_t* w = nullptr;  // [Cout][9*Cin] (tap-major, channel-minor)
+    const half_t* b = nullptr;
+    half_t* y = nullptr;        // NHWC [N][H][W][Cout]
+    int N = 0, Cin = 0, H = 0, W = 0, Cout = 0;
+};
+int small_conv_in_launch(const SmallConvInArgs& a, hipStream_t stream);
+
+struct SmallConvOutArgs {       // 3x3 pad-1 conv to <= 4 output channels from an NHWC fp16 tensor
+    const half_t* x = nullptr;  // [N][H][W][Cin]
+    const half_t* w = nullptr;  // [Cout][9*Cin]
+    const half_t* b = nullptr;
+    int N = 0, H = 0, W = 0, Cin = 0, Cout = 0;
+    int mode = 0;               // 0: UNet out -> denoised NCHW fp32 = x_in - fp16(eps)*sigma (EPS.calculate_denoised, LD.py:1263-1265)
+                                // 1: VAE out  -> NHWC fp32 clamp((v+1)/2, 0, 1) (VAE.process_output, LD.py:6296-6298)
+                                // 2: raw eps NCHW fp32 (tests)
+    const float* x_in = nullptr;   // mode 0: [N][Cout][H][W] fp32
+    const float* sigma = nullptr;  // mode 0: [N]
+    float* out = nullptr;
+};
+int small_conv_out_launch(const SmallConvOutArgs& a, hipStream_t stream);
+
+// timestep lookup + sinusoidal embedding: sigma[N] -> t = argmin |log sigma - log_sigmas| -> [N][dim] fp16 (cos | sin)
+int timestep_embed_launch(const float* sigma, const float* log_sigmas, int n_sig, int N, int dim, half_t* out, float* t_out,
+                          hipStream_t stream);
+
+// weight repack (device side, run once at load)
+int repack_conv3x3_launch(const void* src, int src_is_f32, int O, int I, half_t* dst, hipStream_t stream);  // OIHW -> [O][ky][kx][I]
+int repack_rows_launch(const void* src, int src_is_f32, int rows, int cols, half_t* dst, int geglu_bn, hipStream_t stream);
+int ctx_pad_launch(const void* src, int src_is_f32, int n, int T, int Tp, int D, half_t* dst, hipStream_t stream);
+int fill_half_launch(half_t* dst, size_t n, float v, hipStream_t stream);
+
+// sampler / guidance elementwise (fp32 latents)
+int cfg_combine_launch(const float* den2, float* out, float cfg, size_t n_half, hipStream_t stream);   // out = u + (c-u)*cfg, den2=[u;c]
+int axpby_launch(float* x, float a, const float* y, float b, const float* z, float c, size_t n, hipStream_t stream);  // x = a*x + b*y + c*z

@@ -1,0 +1,297 @@
+// Small / bandwidth-bound kernels around the MFMA path: the 4-channel input convs, the <=4-channel output convs
+// with their fused boundary math, the sigma -> timestep embedding, load-time weight repacks, sampler elementwise.
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ conv_in
+// 3x3 pad-1 conv, Cin <= 4, fp32 NCHW input (the sampler's latent) -> NHWC fp16.  Each thread: one pixel x 8 output
+// channels; the [Cout][9*Cin] filter bank sits in LDS.  Fuses EPS.calculate_input (x / sqrt(sigma^2+1), rounded to
+// fp16 like the reference's `.to(dtype)`, LD.py:5842) or the VAE's 1x1 post_quant_conv (LD.py:3470-3471).
+__global__ __launch_bounds__(256) void small_conv_in_kernel(const SmallConvInArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    half_t* wl = reinterpret_cast<half_t*>(smem_raw);           // [Cout][9*Cin]
+    const int KK = 9 * a.Cin;
+    for (int i = threadIdx.x; i < a.Cout * KK; i += blockDim.x) wl[i] = a.w[i];
+    __syncthreads();
+    const int cgroups = a.Cout >> 3;
+    const long long total = (long long)a.N * a.H * a.W * cgroups;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int cg = (int)(q % cgroups);
+        long long pix = q / cgroups;
+        const int x = (int)(pix % a.W);
+        pix /= a.W;
+        const int y = (int)(pix % a.H), n = (int)(pix / a.H);
+        float inscale = 1.0f;
+        if (a.scale_sigma != nullptr) {
+            const float s = a.scale_sigma[n];
+            inscale = 1.0f / sqrtf(s * s + 1.0f);
+        }
+        float acc[8];
+        {
+            float bb[8];
+            unpack8(ld16(a.b + cg * 8), bb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = bb[j];
+        }
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+            if ((unsigned)iy >= (unsigned)a.H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = x + kx - 1;
+                if ((unsigned)ix >= (unsigned)a.W) continue;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < a.Cin; ++c)
+                    v[c] = (float)(half_t)(a.x[(((long long)n * a.Cin + c) * a.H + iy) * a.W + ix] * inscale);
+                if (a.pre_w != nullptr) {
+                    float t[4];
+                    for (int o = 0; o < a.Cin; ++o) {
+                        float s = (float)a.pre_b[o];
+                        for (int c = 0; c < a.Cin; ++c) s += (float)a.pre_w[o * a.Cin + c] * v[c];
+                        t[o] = (float)(half_t)s;
+                    }
+                    for (int c = 0; c < a.Cin; ++c) v[c] = t[c];
+                }
+                const int tap = (ky * 3 + kx) * a.Cin;
+                for (int c = 0; c < a.Cin; ++c) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += v[c] * (float)wl[(cg * 8 + j) * KK + tap + c];
+                }
+            }
+        }
+        st16(a.y + (((long long)n * a.H + y) * a.W + x) * a.Cout + cg * 8, pack8(acc));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv_out
+// 3x3 pad-1 conv to Cout <= 4 channels from NHWC fp16: one wave per output pixel, lanes stride over the 9*Cin
+// reduction in 16-byte chunks, wave-shuffle reduction.  Fused boundary math per `mode`.
+__global__ __launch_bounds__(256) void small_conv_out_kernel(const SmallConvOutArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long long npix = (long long)a.N * a.H * a.W;
+    const int CH = a.Cin >> 3;           // chunks per tap
+    const int KK = 9 * a.Cin;
+    for (long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (long long)gridDim.x * 4) {
+        const int x = (int)(pix % a.W);
+        const int y = (int)((pix / a.W) % a.H);
+        const int n = (int)(pix / ((long long)a.W * a.H));
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < 9 * CH; c += 64) {
+            const int tap = c / CH, cc = c - tap * CH;
+            const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+            if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) continue;
+            float v[8];
+            unpack8(ld16(a.x + (((long long)n * a.H + iy) * a.W + ix) * a.Cin + cc * 8), v);
+            for (int o = 0; o < a.Cout; ++o) {
+                float w[8];
+                unpack8(ld16(a.w + (long long)o * KK + tap * a.Cin + cc * 8), w);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[o] += v[j] * w[j];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] = wave_sum(acc[o]);
+        if (lane < a.Cout) {
+            const int o = lane;
+            float v = acc[0];
+            if (o == 1) v = acc[1];
+            if (o == 2) v = acc[2];
+            if (o == 3) v = acc[3];
+            v += (float)a.b[o];
+            const long long nchw = (((long long)n * a.Cout + o) * a.H + y) * a.W + x;
+            if (a.mode == 0) {
+                const float eps = (float)(half_t)v;   // the reference's UNet output is an fp16 tensor (.float() after)
+                a.out[nchw] = a.x_in[nchw] - eps * a.sigma[n];
+            } else if (a.mode == 1) {
+                a.out[pix * a.Cout + o] = fminf(fmaxf((v + 1.0f) * 0.5f, 0.f), 1.f);
+            } else {
+                a.out[nchw] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ timestep embedding
+// ModelSamplingDiscrete.timestep (LD.py:1336-1339) + timestep_embedding (LD.py:803-812).  One block per sample.
+__global__ __launch_bounds__(256) void timestep_embed_kernel(const float* sigma, const float* log_sigmas, int n_sig, int dim,
+                                                             half_t* out, float* t_out) {
+    __shared__ float bd[256];
+    __shared__ int bi[256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float ls = logf(sigma[n]);
+    float best = INFINITY;
+    int besti = 0;
+    for (int i = tid; i < n_sig; i += 256) {
+        const float dd = fabsf(ls - log_sigmas[i]);
+        if (dd < best) {
+            best = dd;
+            besti = i;
+        }
+    }
+    bd[tid] = best;
+    bi[tid] = besti;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            // ties resolve to the lowest index, like torch.argmin's first-occurrence rule
+            if (bd[tid + s] < bd[tid] || (bd[tid + s] == bd[tid] && bi[tid + s] < bi[tid])) {
+                bd[tid] = bd[tid + s];
+                bi[tid] = bi[tid + s];
+            }
+        }
+        __syncthreads();
+    }
+    const float t = (float)bi[0];
+    if (tid == 0 && t_out != nullptr) t_out[n] = t;
+    const int half_dim = dim / 2;
+    for (int i = tid; i < half_dim; i += 256) {
+        const float f = expf(-9.210340371976184f * (float)i / (float)half_dim);   // ln(10000)
+        const float arg = t * f;
+        out[(long long)n * dim + i] = (half_t)cosf(arg);
+        out[(long long)n * dim + half_dim + i] = (half_t)sinf(arg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ repack
+template <typename T>
+__global__ void repack_conv3x3_kernel(const T* src, int O, int I, half_t* dst) {
+    const long long total = (long long)O * I * 9;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(q % I);
+        const int tap = (int)((q / I) % 9);
+        const int o = (int)(q / ((long long)I * 9));
+        dst[q] = (half_t)(float)src[((long long)o * I + i) * 9 + tap];
+    }
+}
+
+// copy/convert a [rows][cols] matrix; with geglu_bn > 0 the rows are tile-interleaved for the fused GEGLU epilogue:
+// output tile t (bn rows) = [bn/2 value rows t*bn/2.. | bn/2 gate rows rows/2 + t*bn/2 ..]
+template <typename T>
+__global__ void repack_rows_kernel(const T* src, int rows, int cols, half_t* dst, int bn) {
+    const long long total = (long long)rows * cols;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(q % cols);
+        const int rdst = (int)(q / cols);
+        int rsrc = rdst;
+        if (bn > 0) {
+            const int hb = bn / 2, tile = rdst / bn, within = rdst - tile * bn;
+            rsrc = within < hb ? tile * hb + within : rows / 2 + tile * hb + (within - hb);
+        }
+        dst[q] = (half_t)(float)src[(long long)rsrc * cols + c];
+    }
+}
+
+// context [n][T][D] (fp32 or fp16) -> fp16 [n][Tp][D], rows T..Tp-1 zero (keeps padded keys finite)
+template <typename T>
+__global__ void ctx_pad_kernel(const T* src, int n, int Tk, int Tp, int D, half_t* dst) {
+    const long long total = (long long)n * Tp * D;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int dcol = (int)(q % D);
+        const int t = (int)((q / D) % Tp);
+        const int b = (int)(q / ((long long)D * Tp));
+        dst[q] = t < Tk ? (half_t)(float)src[((long long)b * Tk + t) * D + dcol] : (half_t)0.f;
+    }
+}
+
+__global__ void fill_half_kernel(half_t* dst, size_t n, float v) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) dst[q] = (half_t)v;
+}
+
+// ------------------------------------------------------------------------------------------------ sampler elementwise
+__global__ void cfg_combine_kernel(const float* den2, float* out, float cfg, size_t n) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        const float u = den2[q], c = den2[n + q];
+        out[q] = u + (c - u) * cfg;   // cfg_function, LD.py:2605
+    }
+}
+
+__global__ void axpby_kernel(float* x, float a, const float* y, float b, const float* z, float c, size_t n) {
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+        float v = a * x[q];
+        if (y != nullptr) v += b * y[q];
+        if (z != nullptr) v += c * z[q];
+        x[q] = v;
+    }
+}
+
+inline int grid_for(long long total, int threads, int cap = 4096) {
+    long long b = (total + threads - 1) / threads;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+int small_conv_in_launch(const SmallConvInArgs& a, hipStream_t stream) {
+    if (a.x == nullptr || a.w == nullptr || a.b == nullptr || a.y == nullptr) return LD_ERR_ARG;
+    if (a.Cin < 1 || a.Cin > 4 || (a.Cout & 7) || a.Cout <= 0) return LD_ERR_SHAPE;
+    const size_t lds = (size_t)a.Cout * 9 * a.Cin * sizeof(half_t);
+    if (lds > 64 * 1024) return LD_ERR_SHAPE;
+    const long long total = (long long)a.N * a.H * a.W * (a.Cout >> 3);
+    hipLaunchKernelGGL(small_conv_in_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int small_conv_out_launch(const SmallConvOutArgs& a, hipStream_t stream) {
+    if (a.x == nullptr || a.w == nullptr || a.b == nullptr || a.out == nullptr) return LD_ERR_ARG;
+    if (a.Cout < 1 || a.Cout > 4 || (a.Cin & 7)) return LD_ERR_SHAPE;
+    if (a.mode == 0 && (a.x_in == nullptr || a.sigma == nullptr)) return LD_ERR_ARG;
+    const long long npix = (long long)a.N * a.H * a.W;
+    hipLaunchKernelGGL(small_conv_out_kernel, dim3(grid_for(npix, 4, 8192)), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int timestep_embed_launch(const float* sigma, const float* log_sigmas, int n_sig, int N, int dim, half_t* out, float* t_out,
+                          hipStream_t stream) {
+    if (sigma == nullptr || log_sigmas == nullptr || out == nullptr || N <= 0 || (dim & 1)) return LD_ERR_ARG;
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(N), dim3(256), 0, stream, sigma, log_sigmas, n_sig, dim, out, t_out);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int repack_conv3x3_launch(const void* src, int src_is_f32, int O, int I, half_t* dst, hipStream_t stream) {
+    if (src == nullptr || dst == nullptr) return LD_ERR_ARG;
+    const long long total = (long long)O * I * 9;
+    if (src_is_f32)
+        hipLaunchKernelGGL(repack_conv3x3_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const float*)src, O, I, dst);
+    else
+        hipLaunchKernelGGL(repack_conv3x3_kernel<half_t>, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const half_t*)src, O, I, dst);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int repack_rows_launch(const void* src, int src_is_f32, int rows, int cols, half_t* dst, int geglu_bn, hipStream_t stream) {
+    if (src == nullptr || dst == nullptr) return LD_ERR_ARG;
+    if (geglu_bn > 0 && (rows % geglu_bn)) return LD_ERR_SHAPE;
+    const long long total = (long long)rows * cols;
+    if (src_is_f32)
+        hipLaunchKernelGGL(repack_rows_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const float*)src, rows, cols, dst, geglu_bn);
+    else
+        hipLaunchKernelGGL(repack_rows_kernel<half_t>, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const half_t*)src, rows, cols, dst, geglu_bn);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int ctx_pad_launch(const void* src, int src_is_f32, int n, int T, int Tp, int D, half_t* dst, hipStream_t stream) {
+    if (src == nullptr || dst == nullptr || Tp < T) return LD_ERR_ARG;
+    const long long total = (long long)n * Tp * D;
+    if (src_is_f32)
+        hipLaunchKernelGGL(ctx_pad_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const float*)src, n, T, Tp, D, dst);
+    else
+        hipLaunchKernelGGL(ctx_pad_kernel<half_t>, dim3(grid_for(total, 256)), dim3(256), 0, stream, (const half_t*)src, n, T, Tp, D, dst);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int fill_half_launch(half_t* dst, size_t n, float v, hipStream_t stream) {
+    if (dst == nullptr) return LD_ERR_ARG;
+    hipLaunchKernelGGL(fill_half_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, stream, dst, n, v);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int cfg_combine_launch(const float* den2, float* out, float cfg, size_t n_half, hipStream_t stream) {
+    if (den2 == nullptr || out == nullptr) return LD_ERR_ARG;
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(grid_for((long long)n_half, 256)), dim3(256), 0, stream, den2, out, cfg, n_half);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int axpby_launch(float* x, float a, const float* y, float b, const float* z, float c, size_t n, hipStream_t stream) {
+    if (x == nullptr) return LD_ERR_ARG;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, stream, x, a, y, b, z, c, n);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}

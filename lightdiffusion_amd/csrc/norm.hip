@@ -1,0 +1,267 @@
+// GroupNorm(32) (+SiLU) and LayerNorm for NHWC / token-major fp16 activations.  HBM-bound kernels:
+// 16-byte loads/stores, fp32 statistics, wave-level reductions.
+//
+// GroupNorm takes up to two NHWC sources that are *virtually concatenated* along channels (the UNet's
+// th.cat([h, hs.pop()], 1), LD.py:5749) and writes one contiguous normalised tensor, so the concat is never
+// materialised on its own.  Two launches: (1) partial sums per (image, pixel-chunk, group); (2) finish the
+// statistics (tiny, L2-resident) and apply scale/shift (+SiLU) as one FMA per element.
+#include "kernels.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_SLOTS = 2;   // channel chunks per thread: supports C <= 2 * 256 * 8 = 4096
+
+struct GnArgs {
+    const half_t* x1;
+    const half_t* x2;
+    int C1, C2, HW, P, ppb;   // P pixel-chunks per image, ppb pixels per chunk
+    float* partial;           // [N][P][32][2]
+    const half_t* gamma;
+    const half_t* beta;
+    half_t* y;
+    float eps;
+    int silu;
+};
+
+__device__ __forceinline__ const half_t* gn_src(const GnArgs& a, int n, int pix, int c) {
+    return c < a.C1 ? a.x1 + ((long long)n * a.HW + pix) * a.C1 + c
+                    : a.x2 + ((long long)n * a.HW + pix) * a.C2 + (c - a.C1);
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
+    __shared__ float csum[4096], csq[4096];
+    const int C = a.C1 + a.C2, CH = C >> 3, cpg = C / 32;
+    const int n = blockIdx.y, pc = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < C; i += GN_THREADS) csum[i] = csq[i] = 0.f;
+    __syncthreads();
+    const int rows_par = CH >= GN_THREADS ? 1 : GN_THREADS / CH;
+    const int p_begin = pc * a.ppb, p_end = min(a.HW, p_begin + a.ppb);
+#pragma unroll
+    for (int slot = 0; slot < GN_MAX_SLOTS; ++slot) {
+        int cc, prow;
+        if (CH >= GN_THREADS) {
+            cc = tid + slot * GN_THREADS;
+            prow = 0;
+            if (cc >= CH) break;
+        } else {
+            if (slot > 0) break;
+            cc = tid % CH;
+            prow = tid / CH;
+            if (prow >= rows_par) break;
+        }
+        float s[8], ss[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+        for (int pix = p_begin + prow; pix < p_end; pix += rows_par) {
+            float v[8];
+            unpack8(ld16(gn_src(a, n, pix, cc * 8)), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += v[j];
+                ss[j] += v[j] * v[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&csum[cc * 8 + j], s[j]);
+            atomicAdd(&csq[cc * 8 + j], ss[j]);
+        }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float s = 0.f, ss = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+            s += csum[c];
+            ss += csq[c];
+        }
+        float* o = a.partial + (((long long)n * a.P + pc) * 32 + tid) * 2;
+        o[0] = s;
+        o[1] = ss;
+    }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
+    __shared__ float mean[32], rstd[32];
+    const int C = a.C1 + a.C2, CH = C >> 3, cpg = C / 32;
+    const int n = blockIdx.y, pc = blockIdx.x, tid = threadIdx.x;
+    {   // finish the statistics: 8 lanes per group sweep the P partial slabs in a fixed order
+        const int g = tid >> 3, sub = tid & 7;
+        float s = 0.f, ss = 0.f;
+        const float* pp = a.partial + ((long long)n * a.P * 32 + g) * 2;
+        for (int i = sub; i < a.P; i += 8) {
+            s += pp[(long long)i * 64];
+            ss += pp[(long long)i * 64 + 1];
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            ss += __shfl_xor(ss, o, 64);
+        }
+        if (sub == 0) {
+            const float cnt = (float)cpg * (float)a.HW;
+            const float mu = s / cnt;
+            const float var = fmaxf(ss / cnt - mu * mu, 0.f);
+            mean[g] = mu;
+            rstd[g] = rsqrtf(var + a.eps);
+        }
+    }
+    __syncthreads();
+    const int rows_par = CH >= GN_THREADS ? 1 : GN_THREADS / CH;
+    const int p_begin = pc * a.ppb, p_end = min(a.HW, p_begin + a.ppb);
+#pragma unroll
+    for (int slot = 0; slot < GN_MAX_SLOTS; ++slot) {
+        int cc, prow;
+        if (CH >= GN_THREADS) {
+            cc = tid + slot * GN_THREADS;
+            prow = 0;
+            if (cc >= CH) break;
+        } else {
+            if (slot > 0) break;
+            cc = tid % CH;
+            prow = tid / CH;
+            if (prow >= rows_par) break;
+        }
+        float ga[8], be[8], sc[8], sh[8];
+        unpack8(ld16(a.gamma + cc * 8), ga);
+        unpack8(ld16(a.beta + cc * 8), be);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (cc * 8 + j) / cpg;
+            sc[j] = rstd[g] * ga[j];
+            sh[j] = be[j] - mean[g] * sc[j];
+        }
+        for (int pix = p_begin + prow; pix < p_end; pix += rows_par) {
+            float v[8];
+            unpack8(ld16(gn_src(a, n, pix, cc * 8)), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = v[j] * sc[j] + sh[j];
+                if (a.silu) v[j] = silu_f(v[j]);
+            }
+            st16(a.y + ((long long)n * a.HW + pix) * C + cc * 8, pack8(v));
+        }
+    }
+}
+
+// LayerNorm over the last dim: one wave per row, row held in registers (C <= 64 lanes * 4 chunks * 8 = 2048).
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ gamma,
+                                                         const half_t* __restrict__ beta, half_t* __restrict__ y,
+                                                         int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int CH = C >> 3;
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < CH) {
+            unpack8(ld16(x + (long long)row * C + cc * 8), v[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[i][j];
+        }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < CH) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[i][j] - mu;
+                ss += d * d;
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = lane + i * 64;
+        if (cc < CH) {
+            float ga[8], be[8];
+            unpack8(ld16(gamma + cc * 8), ga);
+            unpack8(ld16(beta + cc * 8), be);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = (v[i][j] - mu) * rs * ga[j] + be[j];
+            st16(y + (long long)row * C + cc * 8, pack8(v[i]));
+        }
+    }
+}
+
+// row softmax in place over fp16 scores (VAE mid-block attention: one head, L = H*W keys)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ s, int cols, long long ld) {
+    __shared__ float red[4];
+    half_t* row = s + (long long)blockIdx.x * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int CH = cols >> 3;
+    float mx = -INFINITY;
+    for (int c = tid; c < CH; c += 256) {
+        float v[8];
+        unpack8(ld16(row + c * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[j]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = tid; c < CH; c += 256) {
+        float v[8];
+        unpack8(ld16(row + c * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += __expf(v[j] - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int c = tid; c < CH; c += 256) {
+        float v[8];
+        unpack8(ld16(row + c * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __expf(v[j] - mx) * inv;
+        st16(row + c * 8, pack8(v));
+    }
+}
+
+}  // namespace
+
+size_t groupnorm_workspace_bytes(int n_img, int HW) {
+    const int P = gn_num_chunks(HW);
+    return (size_t)n_img * P * 32 * 2 * sizeof(float);
+}
+
+int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, const half_t* gamma,
+                     const half_t* beta, float eps, int silu, half_t* y, float* partial, hipStream_t stream) {
+    const int C = C1 + C2;
+    if (x1 == nullptr || y == nullptr || partial == nullptr || gamma == nullptr || beta == nullptr) return LD_ERR_ARG;
+    if (C % 32 || C1 % 8 || C2 % 8 || C > 4096 || C1 <= 0 || (C2 > 0 && x2 == nullptr)) return LD_ERR_SHAPE;
+    GnArgs a;
+    a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.HW = HW;
+    a.P = gn_num_chunks(HW);
+    a.ppb = (HW + a.P - 1) / a.P;
+    a.partial = partial; a.gamma = gamma; a.beta = beta; a.y = y; a.eps = eps; a.silu = silu;
+    dim3 grid(a.P, n_img);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int layernorm_launch(const half_t* x, const half_t* gamma, const half_t* beta, half_t* y, int rows, int C, float eps,
+                     hipStream_t stream) {
+    if (x == nullptr || y == nullptr || gamma == nullptr || beta == nullptr) return LD_ERR_ARG;
+    if (C % 8 || C > 2048 || rows <= 0) return LD_ERR_SHAPE;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, rows, C, eps);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int softmax_rows_launch(half_t* s, int rows, int cols, long long ld, hipStream_t stream) {
+    if (s == nullptr || rows <= 0 || cols % 8 || ld % 8) return LD_ERR_SHAPE;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, s, cols, ld);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}

@@ -1,0 +1,140 @@
+// Host-side runtime shared by the UNet and VAE executors: resident weight table (checkpoint names -> repacked
+// fp16 device tensors), a bump arena for activations with mark/release (stack discipline, deterministic addresses
+// so a whole forward can be captured into a hipGraph), and an Exec context that counts launches / FLOPs and
+// doubles as a dry-run planner (sizes the arena without touching the GPU).
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.h"
+
+enum ParamKind { PK_VEC = 0, PK_MAT = 1, PK_CONV3 = 2, PK_GEGLU_W = 3, PK_GEGLU_B = 4 };
+
+struct ParamSlot {
+    std::string name;
+    int ndim = 0;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int kind = PK_VEC;
+    int geglu_bn = 0;
+    size_t elems = 0, offset = 0;
+    bool loaded = false;
+};
+
+struct ParamTable {
+    std::vector<ParamSlot> slots;
+    std::unordered_map<std::string, int> index;
+    size_t bytes = 0;
+    char* base = nullptr;
+
+    int add(const std::string& name, int kind, std::initializer_list<int64_t> shape, size_t align = 256, int geglu_bn = 0) {
+        ParamSlot s;
+        s.name = name;
+        s.kind = kind;
+        s.geglu_bn = geglu_bn;
+        s.ndim = (int)shape.size();
+        s.elems = 1;
+        int i = 0;
+        for (int64_t d : shape) {
+            s.shape[i++] = d;
+            s.elems *= (size_t)d;
+        }
+        bytes = (bytes + align - 1) / align * align;
+        s.offset = bytes;
+        bytes += s.elems * sizeof(half_t);
+        index[name] = (int)slots.size();
+        slots.push_back(s);
+        return (int)slots.size() - 1;
+    }
+    int finalize() {
+        bytes = (bytes + 255) / 256 * 256;
+        if (hipMalloc((void**)&base, bytes + 256) != hipSuccess) return LD_ERR_HIP;
+        return LD_OK;
+    }
+    void destroy() {
+        if (base) (void)hipFree(base);
+        base = nullptr;
+    }
+    half_t* ptr(int slot) const { return slot < 0 ? nullptr : reinterpret_cast<half_t*>(base + slots[slot].offset); }
+    bool all_loaded() const {
+        for (const auto& s : slots)
+            if (!s.loaded) return false;
+        return true;
+    }
+    int load(const char* name, const void* src, int dtype, hipStream_t stream) {
+        auto it = index.find(name);
+        if (it == index.end() || src == nullptr || base == nullptr) return LD_ERR_ARG;
+        ParamSlot& s = slots[it->second];
+        half_t* dst = ptr(it->second);
+        int st;
+        const int f32 = dtype == 1;
+        switch (s.kind) {
+            case PK_CONV3: st = repack_conv3x3_launch(src, f32, (int)s.shape[0], (int)s.shape[1], dst, stream); break;
+            case PK_GEGLU_W: st = repack_rows_launch(src, f32, (int)s.shape[0], (int)s.shape[1], dst, s.geglu_bn, stream); break;
+            case PK_GEGLU_B: st = repack_rows_launch(src, f32, (int)s.shape[0], 1, dst, s.geglu_bn, stream); break;
+            case PK_MAT: st = repack_rows_launch(src, f32, (int)s.shape[0], (int)(s.elems / s.shape[0]), dst, 0, stream); break;
+            default: st = repack_rows_launch(src, f32, 1, (int)s.elems, dst, 0, stream); break;
+        }
+        if (st == LD_OK) s.loaded = true;
+        return st;
+    }
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    void* alloc(size_t bytes) {
+        off = (off + 255) / 256 * 256;
+        void* p = base + off;
+        off += bytes;
+        if (off > peak) peak = off;
+        return p;
+    }
+    half_t* halfs(size_t n) { return reinterpret_cast<half_t*>(alloc(n * sizeof(half_t))); }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+};
+
+struct Exec {
+    hipStream_t stream = nullptr;
+    bool dry = false;
+    Arena* arena = nullptr;
+    int status = LD_OK;
+    int launches = 0;
+    double flops = 0.0;
+    float* splitk_ws = nullptr;
+    size_t splitk_bytes = 0;
+
+    void note(int st) {
+        if (st != LD_OK && status == LD_OK) status = st;
+    }
+    bool overflow() const { return !dry && arena->peak > arena->cap; }
+
+    void gemm(GemmParams p) {
+        flops += 2.0 * p.M * (double)p.N * p.K * p.batch;
+        if (p.batch == 1) {
+            p.partial = splitk_ws;
+            p.partial_bytes = splitk_bytes;
+        }
+        launches += 1;
+        if (dry || status != LD_OK) return;
+        note(gemm_launch(p, stream));
+    }
+    void groupnorm(const half_t* x1, int C1, const half_t* x2, int C2, int n, int HW, const half_t* g, const half_t* b, float eps,
+                   int silu, half_t* y) {
+        const size_t m = arena->mark();
+        float* ws = reinterpret_cast<float*>(arena->alloc(groupnorm_workspace_bytes(n, HW)));
+        launches += 2;
+        if (!dry && status == LD_OK) note(groupnorm_launch(x1, C1, x2, C2, n, HW, g, b, eps, silu, y, ws, stream));
+        arena->release(m);
+    }
+    void layernorm(const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int C) {
+        launches += 1;
+        if (!dry && status == LD_OK) note(layernorm_launch(x, g, b, y, rows, C, 1e-5f, stream));
+    }
+    void attention(const AttnParams& p) {
+        flops += 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.d;
+        launches += 1;
+        if (!dry && status == LD_OK) note(attention_launch(p, stream));
+    }
+};

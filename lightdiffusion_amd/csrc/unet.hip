@@ -1,0 +1,627 @@
+// SD1.x UNet executor (host side).  Walks the same block structure UNetModel1.__init__ builds (LD.py:5379-5686)
+// and UNetModel1.forward runs (LD.py:5688-5767), but on NHWC fp16 activations — in that layout a feature map IS the
+// [tokens, channels] matrix of the SpatialTransformer, so the reference's 32 NCHW<->NLC transposing copies
+// (LD.py:4251, 4259) disappear, the skip concats are virtual (two-source A loaders), nearest-upsample is an
+// index map inside the conv loader, and every bias / time-embedding add / residual / SiLU / GEGLU is an epilogue.
+#include <cstring>
+
+#include "runtime.h"
+#include "../../include/ld_mi355x.h"
+
+namespace {
+
+struct ResW {
+    std::string prefix;
+    int cin = 0, cout = 0, emb_off = 0;
+    int gn1_g, gn1_b, c1_w, c1_b, emb_w, emb_b, gn2_g, gn2_b, c2_w, c2_b, sk_w = -1, sk_b = -1;
+};
+struct StW {
+    int c = 0, bn = 0, ctx_slot = 0;
+    int gn_g, gn_b, pin_w, pin_b, ln1_g, ln1_b, q1_w, k1_w, v1_w, o1_w, o1_b, ln2_g, ln2_b, q2_w, k2_w, v2_w, o2_w, o2_b, ln3_g,
+        ln3_b, ff1_w, ff1_b, ff2_w, ff2_b, pout_w, pout_b;
+};
+struct ConvW {
+    int cin = 0, cout = 0, w = -1, b = -1;
+};
+enum LayerKind { L_CONV_IN, L_RES, L_ST, L_DOWN, L_UP };
+struct Layer {
+    int kind, idx;
+};
+struct Feat {
+    half_t* p;
+    int C, H, W;
+};
+
+}  // namespace
+
+struct ld_unet {
+    ld_unet_config cfg;
+    ParamTable pt;
+    std::vector<ResW> res;
+    std::vector<StW> st;
+    std::vector<ConvW> convs;
+    std::vector<std::vector<Layer>> in_blocks, out_blocks;
+    std::vector<Layer> mid_block;
+    int te0_w, te0_b, te2_w, te2_b, outn_g, outn_b, outc_w, outc_b;
+    int emb_total = 0, ted = 0;
+    // workspace
+    Arena arena;
+    char* ws_base = nullptr;
+    size_t ws_bytes = 0;
+    float* splitk_ws = nullptr;
+    size_t splitk_bytes = 0;
+    float* log_sigmas = nullptr;   // 1000-entry table, device
+    // context (cross-attention K / V^T per transformer, hoisted out of the step)
+    int max_n = 0, max_h = 0, max_w = 0, max_tok = 0;
+    half_t* ctx16 = nullptr;
+    std::vector<half_t*> ctx_k, ctx_vt;
+    int ctx_n = 0, ctx_tok = 0, ctx_tpad = 0;
+    int plan_n = 0, plan_h = 0, plan_w = 0;   // last shape validated against the reserved arena
+    int last_launches = 0;
+    double last_flops = 0.0;
+};
+
+namespace {
+
+std::string S(const char* fmt, int a = 0, int b = 0) {
+    char buf[160];
+    snprintf(buf, sizeof buf, fmt, a, b);
+    return buf;
+}
+
+int add_res(ld_unet* u, const std::string& p, int cin, int cout) {
+    ParamTable& t = u->pt;
+    ResW r;
+    r.prefix = p;
+    r.cin = cin;
+    r.cout = cout;
+    r.gn1_g = t.add(p + ".in_layers.0.weight", PK_VEC, {cin});
+    r.gn1_b = t.add(p + ".in_layers.0.bias", PK_VEC, {cin});
+    r.c1_w = t.add(p + ".in_layers.2.weight", PK_CONV3, {cout, cin, 3, 3});
+    r.c1_b = t.add(p + ".in_layers.2.bias", PK_VEC, {cout});
+    r.gn2_g = t.add(p + ".out_layers.0.weight", PK_VEC, {cout});
+    r.gn2_b = t.add(p + ".out_layers.0.bias", PK_VEC, {cout});
+    r.c2_w = t.add(p + ".out_layers.3.weight", PK_CONV3, {cout, cout, 3, 3});
+    r.c2_b = t.add(p + ".out_layers.3.bias", PK_VEC, {cout});
+    if (cin != cout) {
+        r.sk_w = t.add(p + ".skip_connection.weight", PK_MAT, {cout, cin, 1, 1});
+        r.sk_b = t.add(p + ".skip_connection.bias", PK_VEC, {cout});
+    }
+    r.emb_off = u->emb_total;
+    u->emb_total += cout;
+    u->res.push_back(r);
+    return (int)u->res.size() - 1;
+}
+
+int add_st(ld_unet* u, const std::string& p, int c) {
+    ParamTable& t = u->pt;
+    const int ctx = u->cfg.context_dim;
+    StW s;
+    s.c = c;
+    s.bn = gemm_pick_bn(8 * c);
+    s.ctx_slot = (int)u->st.size();
+    s.gn_g = t.add(p + ".norm.weight", PK_VEC, {c});
+    s.gn_b = t.add(p + ".norm.bias", PK_VEC, {c});
+    s.pin_w = t.add(p + ".proj_in.weight", PK_MAT, {c, c, 1, 1});
+    s.pin_b = t.add(p + ".proj_in.bias", PK_VEC, {c});
+    const std::string b = p + ".transformer_blocks.0";
+    s.ln1_g = t.add(b + ".norm1.weight", PK_VEC, {c});
+    s.ln1_b = t.add(b + ".norm1.bias", PK_VEC, {c});
+    s.q1_w = t.add(b + ".attn1.to_q.weight", PK_MAT, {c, c});
+    s.k1_w = t.add(b + ".attn1.to_k.weight", PK_MAT, {c, c}, 16);   // contiguous with to_q: one [2C][C] projection
+    s.v1_w = t.add(b + ".attn1.to_v.weight", PK_MAT, {c, c});
+    s.o1_w = t.add(b + ".attn1.to_out.0.weight", PK_MAT, {c, c});
+    s.o1_b = t.add(b + ".attn1.to_out.0.bias", PK_VEC, {c});
+    s.ln2_g = t.add(b + ".norm2.weight", PK_VEC, {c});
+    s.ln2_b = t.add(b + ".norm2.bias", PK_VEC, {c});
+    s.q2_w = t.add(b + ".attn2.to_q.weight", PK_MAT, {c, c});
+    s.k2_w = t.add(b + ".attn2.to_k.weight", PK_MAT, {c, ctx});
+    s.v2_w = t.add(b + ".attn2.to_v.weight", PK_MAT, {c, ctx});
+    s.o2_w = t.add(b + ".attn2.to_out.0.weight", PK_MAT, {c, c});
+    s.o2_b = t.add(b + ".attn2.to_out.0.bias", PK_VEC, {c});
+    s.ln3_g = t.add(b + ".norm3.weight", PK_VEC, {c});
+    s.ln3_b = t.add(b + ".norm3.bias", PK_VEC, {c});
+    s.ff1_w = t.add(b + ".ff.net.0.proj.weight", PK_GEGLU_W, {8 * c, c}, 256, s.bn);
+    s.ff1_b = t.add(b + ".ff.net.0.proj.bias", PK_GEGLU_B, {8 * c}, 256, s.bn);
+    s.ff2_w = t.add(b + ".ff.net.2.weight", PK_MAT, {c, 4 * c});
+    s.ff2_b = t.add(b + ".ff.net.2.bias", PK_VEC, {c});
+    s.pout_w = t.add(p + ".proj_out.weight", PK_MAT, {c, c, 1, 1});
+    s.pout_b = t.add(p + ".proj_out.bias", PK_VEC, {c});
+    u->st.push_back(s);
+    return (int)u->st.size() - 1;
+}
+
+int add_conv(ld_unet* u, const std::string& p, int cin, int cout) {
+    ConvW c;
+    c.cin = cin;
+    c.cout = cout;
+    c.w = u->pt.add(p + ".weight", PK_CONV3, {cout, cin, 3, 3});
+    c.b = u->pt.add(p + ".bias", PK_VEC, {cout});
+    u->convs.push_back(c);
+    return (int)u->convs.size() - 1;
+}
+
+int build(ld_unet* u) {
+    const ld_unet_config& c = u->cfg;
+    if (c.num_levels < 1 || c.num_levels > 8 || c.model_channels % 32 || c.num_heads < 1) return LD_ERR_ARG;
+    const int mc = c.model_channels;
+    u->ted = mc * 4;
+    ParamTable& t = u->pt;
+    u->te0_w = t.add("time_embed.0.weight", PK_MAT, {u->ted, mc});
+    u->te0_b = t.add("time_embed.0.bias", PK_VEC, {u->ted});
+    u->te2_w = t.add("time_embed.2.weight", PK_MAT, {u->ted, u->ted});
+    u->te2_b = t.add("time_embed.2.bias", PK_VEC, {u->ted});
+    u->in_blocks.push_back({{L_CONV_IN, add_conv(u, "input_blocks.0.0", c.in_channels, mc)}});
+    int ch = mc, idx = 1, td = 0;
+    std::vector<int> chans{mc};
+    for (int lvl = 0; lvl < c.num_levels; ++lvl) {
+        for (int r = 0; r < c.num_res_blocks[lvl]; ++r) {
+            std::vector<Layer> L;
+            L.push_back({L_RES, add_res(u, S("input_blocks.%d.0", idx), ch, c.channel_mult[lvl] * mc)});
+            ch = c.channel_mult[lvl] * mc;
+            if (c.transformer_depth[td++] > 0) L.push_back({L_ST, add_st(u, S("input_blocks.%d.1", idx), ch)});
+            u->in_blocks.push_back(L);
+            chans.push_back(ch);
+            ++idx;
+        }
+        if (lvl != c.num_levels - 1) {
+            u->in_blocks.push_back({{L_DOWN, add_conv(u, S("input_blocks.%d.0.op", idx), ch, ch)}});
+            chans.push_back(ch);
+            ++idx;
+        }
+    }
+    u->mid_block.push_back({L_RES, add_res(u, "middle_block.0", ch, ch)});
+    if (c.transformer_depth_middle > 0) u->mid_block.push_back({L_ST, add_st(u, "middle_block.1", ch)});
+    u->mid_block.push_back({L_RES, add_res(u, "middle_block.2", ch, ch)});
+    // the reference pops transformer_depth_output from the END of the list (LD.py:5621)
+    int n_out = 0;
+    for (int lvl = 0; lvl < c.num_levels; ++lvl) n_out += c.num_res_blocks[lvl] + 1;
+    int tdo = n_out;
+    idx = 0;
+    for (int lvl = c.num_levels - 1; lvl >= 0; --lvl) {
+        for (int i = 0; i <= c.num_res_blocks[lvl]; ++i) {
+            const int ich = chans.back();
+            chans.pop_back();
+            std::vector<Layer> L;
+            L.push_back({L_RES, add_res(u, S("output_blocks.%d.0", idx), ch + ich, mc * c.channel_mult[lvl])});
+            ch = mc * c.channel_mult[lvl];
+            int j = 1;
+            if (c.transformer_depth_output[--tdo] > 0) {
+                L.push_back({L_ST, add_st(u, S("output_blocks.%d.%d", idx, j), ch)});
+                ++j;
+            }
+            if (lvl && i == c.num_res_blocks[lvl]) L.push_back({L_UP, add_conv(u, S("output_blocks.%d.%d.conv", idx, j), ch, ch)});
+            u->out_blocks.push_back(L);
+            ++idx;
+        }
+    }
+    u->outn_g = t.add("out.0.weight", PK_VEC, {ch});
+    u->outn_b = t.add("out.0.bias", PK_VEC, {ch});
+    u->outc_w = t.add("out.2.weight", PK_CONV3, {c.out_channels, mc, 3, 3});
+    u->outc_b = t.add("out.2.bias", PK_VEC, {c.out_channels});
+    // the 22 emb_layers Linears as ONE [sum(Cout)][4*mc] matrix (tightly packed) -> one GEMM per step
+    for (size_t i = 0; i < u->res.size(); ++i)
+        u->res[i].emb_w = t.add(u->res[i].prefix + ".emb_layers.1.weight", PK_MAT, {u->res[i].cout, u->ted}, i == 0 ? 256 : 16);
+    for (size_t i = 0; i < u->res.size(); ++i)
+        u->res[i].emb_b = t.add(u->res[i].prefix + ".emb_layers.1.bias", PK_VEC, {u->res[i].cout}, i == 0 ? 256 : 16);
+    return t.finalize();
+}
+
+// ---------------------------------------------------------------------------------------------------- forward pieces
+struct Run {
+    ld_unet* u;
+    Exec ex;
+    int n;
+    const half_t* emb_all;   // [n][emb_total]
+    half_t* P(int slot) const { return u->pt.ptr(slot); }
+
+    half_t* conv3(const half_t* x1, int C1, const half_t* x2, int C2, int Hs, int Ws, int Hv, int Wv, int stride, int wslot, int bslot,
+                  int cout, const half_t* rowvec, int ldrv, const half_t* R, half_t* out, int* Ho_, int* Wo_, int ksize = 3) {
+        const int Ho = ksize == 3 ? (Hv - 1) / stride + 1 : Hv, Wo = ksize == 3 ? (Wv - 1) / stride + 1 : Wv;
+        GemmParams p;
+        p.conv = 1;
+        p.ksize = ksize;
+        p.A = x1; p.A2 = x2; p.C1 = C1; p.C2 = C2;
+        p.Hs = Hs; p.Ws = Ws; p.Hv = Hv; p.Wv = Wv; p.Ho = Ho; p.Wo = Wo; p.stride = stride;
+        p.W = P(wslot); p.ldw = ksize * ksize * (C1 + C2);
+        p.M = n * Ho * Wo; p.N = cout; p.K = ksize * ksize * (C1 + C2);
+        p.bias_n = P(bslot);
+        p.rowvec = rowvec; p.rows_per_vec = Ho * Wo; p.ldrv = ldrv;
+        p.R = R; p.ldr = cout;
+        p.C = out; p.ldc = cout;
+        ex.gemm(p);
+        if (Ho_) *Ho_ = Ho;
+        if (Wo_) *Wo_ = Wo;
+        return out;
+    }
+
+    void linear(const half_t* x, int lda, int wslot, int bslot, const half_t* R, half_t* y, int M, int N, int K, int act = 0, int bn = 0) {
+        GemmParams p;
+        p.A = x; p.lda = lda;
+        p.W = P(wslot); p.ldw = K;
+        p.M = M; p.N = N; p.K = K;
+        p.bias_n = bslot >= 0 ? P(bslot) : nullptr;
+        p.R = R; p.ldr = (act == 2 ? N / 2 : N);
+        p.act = act; p.bn = bn;
+        p.C = y; p.ldc = (act == 2 ? N / 2 : N);
+        ex.gemm(p);
+    }
+
+    // ResBlock1._forward, LD.py:5273-5287.  Input = channel concat of (x1,C1) and (x2,C2).
+    Feat resblock(const ResW& r, const half_t* x1, int C1, const half_t* x2, int C2, int H, int W) {
+        Arena& ar = *ex.arena;
+        const size_t M = (size_t)n * H * W;
+        half_t* out = ar.halfs(M * r.cout);
+        const size_t mk = ar.mark();
+        half_t* g1 = ar.halfs(M * r.cin);
+        ex.groupnorm(x1, C1, x2, C2, n, H * W, P(r.gn1_g), P(r.gn1_b), 1e-5f, 1, g1);
+        half_t* h1 = ar.halfs(M * r.cout);
+        conv3(g1, r.cin, nullptr, 0, H, W, H, W, 1, r.c1_w, r.c1_b, r.cout, emb_all + r.emb_off, u->emb_total, nullptr, h1, nullptr, nullptr);
+        half_t* g2 = g1;   // g1 is dead once conv1 has consumed it (stream order); reuse when it is large enough
+        if (r.cout > r.cin) g2 = ar.halfs(M * r.cout);
+        ex.groupnorm(h1, r.cout, nullptr, 0, n, H * W, P(r.gn2_g), P(r.gn2_b), 1e-5f, 1, g2);
+        const half_t* skip = x1;
+        if (r.sk_w >= 0) {
+            half_t* sk = ar.halfs(M * r.cout);
+            conv3(x1, C1, x2, C2, H, W, H, W, 1, r.sk_w, r.sk_b, r.cout, nullptr, 0, nullptr, sk, nullptr, nullptr, 1);
+            skip = sk;
+        }
+        conv3(g2, r.cout, nullptr, 0, H, W, H, W, 1, r.c2_w, r.c2_b, r.cout, nullptr, 0, skip, out, nullptr, nullptr);
+        ar.release(mk);
+        return {out, r.cout, H, W};
+    }
+
+    // SpatialTransformer.forward (LD.py:4239-4262) around BasicTransformerBlock._forward (LD.py:4117-4162)
+    Feat transformer(const StW& s, const half_t* x, int H, int W) {
+        Arena& ar = *ex.arena;
+        const int C = s.c, L = H * W, heads = u->cfg.num_heads, d = C / heads;
+        const int M = n * L;
+        half_t* out = ar.halfs((size_t)M * C);
+        const size_t mk = ar.mark();
+        half_t* g = ar.halfs((size_t)M * C);
+        ex.groupnorm(x, C, nullptr, 0, n, L, P(s.gn_g), P(s.gn_b), 1e-6f, 0, g);
+        half_t* t = ar.halfs((size_t)M * C);
+        linear(g, C, s.pin_w, s.pin_b, nullptr, t, M, C, C);
+        half_t* nrm = g;   // reuse
+        // ---- self attention: x += to_out(attn(LN1(x)))
+        ex.layernorm(t, P(s.ln1_g), P(s.ln1_b), nrm, M, C);
+        half_t* qk = ar.halfs((size_t)M * 2 * C);
+        linear(nrm, C, s.q1_w, -1, nullptr, qk, M, 2 * C, C);
+        half_t* vt = ar.halfs((size_t)M * C);
+        {   // V^T[b] = Wv · LN(x)_b^T  -> [C][L] per sample (swapped GEMM: the weight is the row operand)
+            GemmParams p;
+            p.A = P(s.v1_w); p.lda = C; p.sA = 0;
+            p.W = nrm; p.ldw = C; p.sW = (long long)L * C;
+            p.M = C; p.N = L; p.K = C; p.batch = n;
+            p.C = vt; p.ldc = L; p.sC = (long long)C * L;
+            ex.gemm(p);
+        }
+        half_t* ao = ar.halfs((size_t)M * C);
+        {
+            AttnParams a;
+            a.Q = qk; a.ldq = 2 * C; a.sQ = (long long)L * 2 * C;
+            a.K = qk + C; a.ldk = 2 * C; a.sK = (long long)L * 2 * C;
+            a.Vt = vt; a.ldvt = L; a.sV = (long long)C * L;
+            a.O = ao; a.ldo = C; a.sO = (long long)L * C;
+            a.B = n; a.H = heads; a.Lq = L; a.Lk = L; a.d = d;
+            a.scale = 1.0f / sqrtf((float)d);
+            ex.attention(a);
+        }
+        linear(ao, C, s.o1_w, s.o1_b, t, t, M, C, C);
+        // ---- cross attention against the hoisted context K / V^T
+        ex.layernorm(t, P(s.ln2_g), P(s.ln2_b), nrm, M, C);
+        half_t* q2 = qk;   // reuse
+        linear(nrm, C, s.q2_w, -1, nullptr, q2, M, C, C);
+        {
+            const int Tp = u->ctx_tpad;
+            AttnParams a;
+            a.Q = q2; a.ldq = C; a.sQ = (long long)L * C;
+            a.K = u->ctx_k[s.ctx_slot]; a.ldk = C; a.sK = (long long)Tp * C;
+            a.Vt = u->ctx_vt[s.ctx_slot]; a.ldvt = Tp; a.sV = (long long)C * Tp;
+            a.O = ao; a.ldo = C; a.sO = (long long)L * C;
+            a.B = n; a.H = heads; a.Lq = L; a.Lk = u->ctx_tok; a.d = d;
+            a.scale = 1.0f / sqrtf((float)d);
+            ex.attention(a);
+        }
+        linear(ao, C, s.o2_w, s.o2_b, t, t, M, C, C);
+        // ---- GEGLU feed-forward: x = ff2(a * gelu(gate)) + x
+        ex.layernorm(t, P(s.ln3_g), P(s.ln3_b), nrm, M, C);
+        half_t* ff = ar.halfs((size_t)M * 4 * C);
+        linear(nrm, C, s.ff1_w, s.ff1_b, nullptr, ff, M, 8 * C, C, 2, s.bn);
+        linear(ff, 4 * C, s.ff2_w, s.ff2_b, t, t, M, C, 4 * C);
+        linear(t, C, s.pout_w, s.pout_b, x, out, M, C, C);
+        ar.release(mk);
+        return {out, C, H, W};
+    }
+};
+
+int check_attn_shapes(const ld_unet* u, int h, int w) {
+    // every attention level needs tokens % 8 == 0 (V^T rows are copied in 16-byte chunks)
+    int H = h, W = w;
+    int td = 0;
+    for (int lvl = 0; lvl < u->cfg.num_levels; ++lvl) {
+        bool any = false;
+        for (int r = 0; r < u->cfg.num_res_blocks[lvl]; ++r) any |= u->cfg.transformer_depth[td++] > 0;
+        if (lvl == u->cfg.num_levels - 1 && u->cfg.transformer_depth_middle > 0) any = true;
+        if (any && ((H * W) & 7)) return LD_ERR_SHAPE;
+        if (lvl != u->cfg.num_levels - 1) {
+            H = (H - 1) / 2 + 1;
+            W = (W - 1) / 2 + 1;
+        }
+    }
+    return LD_OK;
+}
+
+int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, hipStream_t stream,
+                size_t* dry_peak = nullptr) {
+    Run R;
+    R.u = u;
+    R.n = n;
+    Exec& ex = R.ex;
+    ex.stream = stream;
+    ex.dry = dry;
+    Arena plan;   // dry runs bump a private arena (no base): sizes only
+    ex.arena = dry ? &plan : &u->arena;
+    ex.splitk_ws = u->splitk_ws;
+    ex.splitk_bytes = u->splitk_bytes;
+    Arena& ar = *ex.arena;
+    ar.release(0);
+    const ld_unet_config& c = u->cfg;
+    const int mc = c.model_channels, ted = u->ted;
+
+    // timestep embedding -> time_embed MLP -> all ResBlock emb_layers at once (every consumer applies SiLU first)
+    half_t* temb = ar.halfs((size_t)n * mc);
+    ex.launches += 1;
+    if (!dry) ex.note(timestep_embed_launch(sigma, u->log_sigmas, 1000, n, mc, temb, nullptr, stream));
+    half_t* e1 = ar.halfs((size_t)n * ted);
+    R.linear(temb, mc, u->te0_w, u->te0_b, nullptr, e1, n, ted, mc, 1);
+    half_t* semb = ar.halfs((size_t)n * ted);
+    R.linear(e1, ted, u->te2_w, u->te2_b, nullptr, semb, n, ted, ted, 1);
+    half_t* emb_all = ar.halfs((size_t)n * u->emb_total);
+    R.linear(semb, ted, u->res[0].emb_w, u->res[0].emb_b, nullptr, emb_all, n, u->emb_total, ted);
+    R.emb_all = emb_all;
+
+    auto run_layers = [&](const std::vector<Layer>& layers, Feat f, const half_t* x2, int C2, int outH, int outW) -> Feat {
+        for (const Layer& L : layers) {
+            switch (L.kind) {
+                case L_RES: {
+                    f = R.resblock(u->res[L.idx], f.p, f.C, x2, C2, f.H, f.W);
+                    x2 = nullptr;
+                    C2 = 0;
+                    break;
+                }
+                case L_ST: f = R.transformer(u->st[L.idx], f.p, f.H, f.W); break;
+                case L_DOWN: {
+                    const ConvW& cw = u->convs[L.idx];
+                    const int Ho = (f.H - 1) / 2 + 1, Wo = (f.W - 1) / 2 + 1;
+                    half_t* o = ar.halfs((size_t)n * Ho * Wo * cw.cout);
+                    R.conv3(f.p, f.C, nullptr, 0, f.H, f.W, f.H, f.W, 2, cw.w, cw.b, cw.cout, nullptr, 0, nullptr, o, nullptr, nullptr);
+                    f = {o, cw.cout, Ho, Wo};
+                    break;
+                }
+                case L_UP: {   // Upsample1: nearest resize to the next skip's H x W, then conv (LD.py:5141-5152)
+                    const ConvW& cw = u->convs[L.idx];
+                    const int Hv = outH > 0 ? outH : f.H * 2, Wv = outW > 0 ? outW : f.W * 2;
+                    half_t* o = ar.halfs((size_t)n * Hv * Wv * cw.cout);
+                    R.conv3(f.p, f.C, nullptr, 0, f.H, f.W, Hv, Wv, 1, cw.w, cw.b, cw.cout, nullptr, 0, nullptr, o, nullptr, nullptr);
+                    f = {o, cw.cout, Hv, Wv};
+                    break;
+                }
+                default: break;
+            }
+        }
+        return f;
+    };
+
+    std::vector<Feat> hs;
+    Feat f{nullptr, 0, h, w};
+    {   // input_blocks[0]: conv_in fused with EPS.calculate_input and the fp32 NCHW -> fp16 NHWC layout change
+        const ConvW& cw = u->convs[u->in_blocks[0][0].idx];
+        half_t* o = ar.halfs((size_t)n * h * w * mc);
+        SmallConvInArgs a;
+        a.x = x; a.scale_sigma = sigma; a.w = u->pt.ptr(cw.w); a.b = u->pt.ptr(cw.b); a.y = o;
+        a.N = n; a.Cin = c.in_channels; a.H = h; a.W = w; a.Cout = mc;
+        ex.launches += 1;
+        ex.flops += 2.0 * n * h * w * mc * 9.0 * c.in_channels;
+        if (!dry) ex.note(small_conv_in_launch(a, stream));
+        f = {o, mc, h, w};
+        hs.push_back(f);
+    }
+    for (size_t b = 1; b < u->in_blocks.size(); ++b) {
+        f = run_layers(u->in_blocks[b], f, nullptr, 0, 0, 0);
+        hs.push_back(f);
+    }
+    f = run_layers(u->mid_block, f, nullptr, 0, 0, 0);
+    for (size_t b = 0; b < u->out_blocks.size(); ++b) {
+        const Feat skip = hs.back();
+        hs.pop_back();
+        if (skip.H != f.H || skip.W != f.W) ex.note(LD_ERR_SHAPE);
+        const int oh = hs.empty() ? 0 : hs.back().H, ow = hs.empty() ? 0 : hs.back().W;
+        f = run_layers(u->out_blocks[b], f, skip.p, skip.C, oh, ow);
+    }
+    {   // out: GroupNorm + SiLU, 3x3 conv to 4 channels fused with EPS.calculate_denoised, back to fp32 NCHW
+        half_t* g = ar.halfs((size_t)n * f.H * f.W * f.C);
+        ex.groupnorm(f.p, f.C, nullptr, 0, n, f.H * f.W, u->pt.ptr(u->outn_g), u->pt.ptr(u->outn_b), 1e-5f, 1, g);
+        SmallConvOutArgs a;
+        a.x = g; a.w = u->pt.ptr(u->outc_w); a.b = u->pt.ptr(u->outc_b);
+        a.N = n; a.H = f.H; a.W = f.W; a.Cin = f.C; a.Cout = c.out_channels;
+        a.mode = eps_only ? 2 : 0;
+        a.x_in = x; a.sigma = sigma; a.out = out;
+        ex.launches += 1;
+        ex.flops += 2.0 * n * f.H * f.W * f.C * 9.0 * c.out_channels;
+        if (!dry) ex.note(small_conv_out_launch(a, stream));
+    }
+    u->last_launches = ex.launches;
+    u->last_flops = ex.flops;
+    if (dry_peak) *dry_peak = ar.peak;
+    return ex.status;
+}
+
+}  // namespace
+
+// ==================================================================================================== C ABI
+extern "C" {
+
+int ld_unet_create(const ld_unet_config* cfg, ld_unet** out) {
+    if (cfg == nullptr || out == nullptr) return LD_ERR_ARG;
+    ld_unet* u = new ld_unet();
+    u->cfg = *cfg;
+    const int st = build(u);
+    if (st != LD_OK) {
+        u->pt.destroy();
+        delete u;
+        return st;
+    }
+    // sigma table of ModelSamplingDiscrete (LD.py:1300-1326): scaled-linear betas in fp64, log taken in fp64
+    std::vector<float> ls(1000);
+    {
+        const double b0 = sqrt(0.00085), b1 = sqrt(0.012);
+        double ac = 1.0;
+        for (int i = 0; i < 1000; ++i) {
+            const double sb = b0 + (b1 - b0) * (double)i / 999.0;
+            ac *= 1.0 - sb * sb;
+            ls[i] = (float)log(sqrt((1.0 - ac) / ac));
+        }
+    }
+    if (hipMalloc((void**)&u->log_sigmas, 1000 * sizeof(float)) != hipSuccess ||
+        hipMemcpy(u->log_sigmas, ls.data(), 1000 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        u->pt.destroy();
+        delete u;
+        return LD_ERR_HIP;
+    }
+    *out = u;
+    return LD_OK;
+}
+
+void ld_unet_destroy(ld_unet* u) {
+    if (u == nullptr) return;
+    u->pt.destroy();
+    if (u->ws_base) (void)hipFree(u->ws_base);
+    if (u->log_sigmas) (void)hipFree(u->log_sigmas);
+    delete u;
+}
+
+int ld_unet_param_count(const ld_unet* u) { return u ? (int)u->pt.slots.size() : 0; }
+
+int ld_unet_param_info(const ld_unet* u, int i, const char** name, int* ndim, int64_t shape[4]) {
+    if (u == nullptr || i < 0 || i >= (int)u->pt.slots.size()) return LD_ERR_ARG;
+    const ParamSlot& s = u->pt.slots[i];
+    if (name) *name = s.name.c_str();
+    if (ndim) *ndim = s.ndim;
+    if (shape)
+        for (int k = 0; k < 4; ++k) shape[k] = s.shape[k];
+    return LD_OK;
+}
+
+int ld_unet_load_param(ld_unet* u, const char* name, const void* src, int dtype, void* stream) {
+    if (u == nullptr || name == nullptr) return LD_ERR_ARG;
+    return u->pt.load(name, src, dtype, (hipStream_t)stream);
+}
+
+size_t ld_unet_workspace_bytes(const ld_unet* u) { return u ? u->ws_bytes : 0; }
+size_t ld_unet_weight_bytes(const ld_unet* u) { return u ? u->pt.bytes : 0; }
+
+int ld_unet_reserve(ld_unet* u, int max_n, int max_h, int max_w, int max_tok) {
+    if (u == nullptr || max_n < 1 || max_h < 1 || max_w < 1 || max_tok < 1) return LD_ERR_ARG;
+    if (u->ws_base) {
+        (void)hipFree(u->ws_base);
+        u->ws_base = nullptr;
+    }
+    // plan: dry-run the executor to find the activation peak
+    u->arena = Arena();
+    u->plan_n = u->plan_h = u->plan_w = 0;
+    u->ctx_tok = max_tok;
+    u->ctx_tpad = (max_tok + 7) & ~7;
+    u->ctx_k.assign(u->st.size(), nullptr);
+    u->ctx_vt.assign(u->st.size(), nullptr);
+    size_t peak = 0;
+    int st = run_forward(u, true, nullptr, nullptr, nullptr, max_n, max_h, max_w, 0, nullptr, &peak);
+    if (st != LD_OK) return st;
+    const size_t act = (peak + 4095) / 4096 * 4096;
+    const size_t tpad = (size_t)u->ctx_tpad;
+    size_t ctxb = ((size_t)max_n * tpad * u->cfg.context_dim * sizeof(half_t) + 255) / 256 * 256;
+    for (const StW& s : u->st) ctxb += 2 * (((size_t)max_n * tpad * s.c * sizeof(half_t) + 255) / 256 * 256);
+    u->splitk_bytes = (size_t)64 << 20;
+    u->ws_bytes = act + ctxb + u->splitk_bytes + 4096;
+    if (hipMalloc((void**)&u->ws_base, u->ws_bytes) != hipSuccess) {
+        u->ws_base = nullptr;
+        return LD_ERR_HIP;
+    }
+    char* p = u->ws_base;
+    u->arena.base = p;
+    u->arena.cap = act;
+    u->arena.off = u->arena.peak = 0;
+    p += act;
+    u->splitk_ws = reinterpret_cast<float*>(p);
+    p += u->splitk_bytes;
+    u->ctx16 = reinterpret_cast<half_t*>(p);
+    p += ((size_t)max_n * tpad * u->cfg.context_dim * sizeof(half_t) + 255) / 256 * 256;
+    for (size_t i = 0; i < u->st.size(); ++i) {
+        const size_t b = ((size_t)max_n * tpad * u->st[i].c * sizeof(half_t) + 255) / 256 * 256;
+        u->ctx_k[i] = reinterpret_cast<half_t*>(p);
+        p += b;
+        u->ctx_vt[i] = reinterpret_cast<half_t*>(p);
+        p += b;
+    }
+    u->max_n = max_n;
+    u->max_h = max_h;
+    u->max_w = max_w;
+    u->max_tok = max_tok;
+    u->ctx_n = 0;
+    return LD_OK;
+}
+
+int ld_unet_set_context(ld_unet* u, const void* ctx, int dtype, int n, int tokens, void* stream_) {
+    if (u == nullptr || ctx == nullptr) return LD_ERR_ARG;
+    if (u->ws_base == nullptr || !u->pt.all_loaded()) return LD_ERR_STATE;
+    if (n < 1 || n > u->max_n || tokens < 1 || tokens > u->max_tok) return LD_ERR_SHAPE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int D = u->cfg.context_dim, Tp = (tokens + 7) & ~7;
+    int st = ctx_pad_launch(ctx, dtype == LD_F32, n, tokens, Tp, D, u->ctx16, stream);
+    if (st != LD_OK) return st;
+    for (size_t i = 0; i < u->st.size(); ++i) {
+        const StW& s = u->st[i];
+        GemmParams k;   // K = ctx · Wk^T : [n*Tp][C]
+        k.A = u->ctx16; k.lda = D;
+        k.W = u->pt.ptr(s.k2_w); k.ldw = D;
+        k.M = n * Tp; k.N = s.c; k.K = D;
+        k.C = u->ctx_k[i]; k.ldc = s.c;
+        st = gemm_launch(k, stream);
+        if (st != LD_OK) return st;
+        GemmParams v;   // V^T[b] = Wv · ctx_b^T : [C][Tp]
+        v.A = u->pt.ptr(s.v2_w); v.lda = D; v.sA = 0;
+        v.W = u->ctx16; v.ldw = D; v.sW = (long long)Tp * D;
+        v.M = s.c; v.N = Tp; v.K = D; v.batch = n;
+        v.C = u->ctx_vt[i]; v.ldc = Tp; v.sC = (long long)s.c * Tp;
+        st = gemm_launch(v, stream);
+        if (st != LD_OK) return st;
+    }
+    u->ctx_n = n;
+    u->ctx_tok = tokens;
+    u->ctx_tpad = Tp;
+    return LD_OK;
+}
+
+int ld_unet_forward(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, void* stream) {
+    if (u == nullptr || x == nullptr || sigma == nullptr || out == nullptr) return LD_ERR_ARG;
+    if (u->ws_base == nullptr || !u->pt.all_loaded() || u->ctx_n == 0) return LD_ERR_STATE;
+    if (n != u->ctx_n) return LD_ERR_SHAPE;
+    if (n > u->max_n || h < 1 || w < 1) return LD_ERR_SHAPE;
+    int st = check_attn_shapes(u, h, w);
+    if (st != LD_OK) return st;
+    if (n != u->plan_n || h != u->plan_h || w != u->plan_w) {   // new shape: plan it on the host before touching the GPU
+        size_t peak = 0;
+        st = run_forward(u, true, nullptr, nullptr, nullptr, n, h, w, eps_only, nullptr, &peak);
+        if (st != LD_OK) return st;
+        if (peak > u->arena.cap) return LD_ERR_SHAPE;
+        u->plan_n = n;
+        u->plan_h = h;
+        u->plan_w = w;
+    }
+    return run_forward(u, false, x, sigma, out, n, h, w, eps_only, (hipStream_t)stream);
+}
+
+int ld_unet_last_launches(const ld_unet* u) { return u ? u->last_launches : 0; }
+double ld_unet_last_flops(const ld_unet* u) { return u ? u->last_flops : 0.0; }
+
+}  // extern "C"

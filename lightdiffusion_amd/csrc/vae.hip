@@ -1,0 +1,358 @@
+// KL-VAE decoder executor: post_quant_conv + Decoder.forward (LD.py:3470-3473, 3857-3882) + VAE.decode's clamp and
+// NHWC output (LD.py:6357-6381), on NHWC fp16 activations with the same kernels as the UNet.
+// The single-head d=512 mid-block attention (AttnBlock, LD.py:3605-3642) is too wide for the flash kernel's
+// register tile, so it runs as three MFMA GEMMs around a row softmax: S = alpha·Q·K^T, P = softmax(S), O = P·V
+// with V^T produced directly by a swapped projection GEMM.
+#include <cstring>
+
+#include "runtime.h"
+#include "../../include/ld_mi355x.h"
+
+namespace {
+struct VResW {
+    int cin, cout;
+    int n1_g, n1_b, c1_w, c1_b, n2_g, n2_b, c2_w, c2_b, nin_w = -1, nin_b = -1;
+};
+}  // namespace
+
+struct ld_vae {
+    ld_vae_config cfg;
+    ParamTable pt;
+    int pq_w, pq_b, cin_w, cin_b;
+    VResW mid1, mid2;
+    int an_g, an_b, aq_w, aq_b, ak_w, ak_b, av_w, av_b, ao_w, ao_b;
+    std::vector<std::vector<VResW>> up;   // [level][block]
+    std::vector<int> ups_w, ups_b;        // [level] (-1 at level 0)
+    int no_g, no_b, co_w, co_b;
+    int block_in0 = 0;
+    Arena arena;
+    char* ws_base = nullptr;
+    size_t ws_bytes = 0;
+    float* splitk_ws = nullptr;
+    size_t splitk_bytes = 0;
+    int plan_b = 0, plan_h = 0, plan_w = 0;
+    int last_launches = 0;
+    double last_flops = 0.0;
+};
+
+namespace {
+
+VResW add_vres(ld_vae* v, const std::string& p, int cin, int cout) {
+    ParamTable& t = v->pt;
+    VResW r;
+    r.cin = cin;
+    r.cout = cout;
+    r.n1_g = t.add(p + ".norm1.weight", PK_VEC, {cin});
+    r.n1_b = t.add(p + ".norm1.bias", PK_VEC, {cin});
+    r.c1_w = t.add(p + ".conv1.weight", PK_CONV3, {cout, cin, 3, 3});
+    r.c1_b = t.add(p + ".conv1.bias", PK_VEC, {cout});
+    r.n2_g = t.add(p + ".norm2.weight", PK_VEC, {cout});
+    r.n2_b = t.add(p + ".norm2.bias", PK_VEC, {cout});
+    r.c2_w = t.add(p + ".conv2.weight", PK_CONV3, {cout, cout, 3, 3});
+    r.c2_b = t.add(p + ".conv2.bias", PK_VEC, {cout});
+    if (cin != cout) {
+        r.nin_w = t.add(p + ".nin_shortcut.weight", PK_MAT, {cout, cin, 1, 1});
+        r.nin_b = t.add(p + ".nin_shortcut.bias", PK_VEC, {cout});
+    }
+    return r;
+}
+
+int build(ld_vae* v) {
+    const ld_vae_config& c = v->cfg;
+    if (c.num_levels < 1 || c.num_levels > 8 || c.z_channels < 1 || c.z_channels > 4 || c.out_ch < 1 || c.out_ch > 4) return LD_ERR_ARG;
+    ParamTable& t = v->pt;
+    const int z = c.z_channels;
+    v->pq_w = t.add("post_quant_conv.weight", PK_MAT, {z, z, 1, 1});
+    v->pq_b = t.add("post_quant_conv.bias", PK_VEC, {z});
+    int bi = c.ch * c.ch_mult[c.num_levels - 1];
+    if (bi % 64) return LD_ERR_SHAPE;
+    v->block_in0 = bi;
+    v->cin_w = t.add("decoder.conv_in.weight", PK_CONV3, {bi, z, 3, 3});
+    v->cin_b = t.add("decoder.conv_in.bias", PK_VEC, {bi});
+    v->mid1 = add_vres(v, "decoder.mid.block_1", bi, bi);
+    v->an_g = t.add("decoder.mid.attn_1.norm.weight", PK_VEC, {bi});
+    v->an_b = t.add("decoder.mid.attn_1.norm.bias", PK_VEC, {bi});
+    v->aq_w = t.add("decoder.mid.attn_1.q.weight", PK_MAT, {bi, bi, 1, 1});
+    v->ak_w = t.add("decoder.mid.attn_1.k.weight", PK_MAT, {bi, bi, 1, 1}, 16);   // [q;k] as one [2C][C] projection
+    v->aq_b = t.add("decoder.mid.attn_1.q.bias", PK_VEC, {bi});
+    v->ak_b = t.add("decoder.mid.attn_1.k.bias", PK_VEC, {bi}, 16);
+    v->av_w = t.add("decoder.mid.attn_1.v.weight", PK_MAT, {bi, bi, 1, 1});
+    v->av_b = t.add("decoder.mid.attn_1.v.bias", PK_VEC, {bi});
+    v->ao_w = t.add("decoder.mid.attn_1.proj_out.weight", PK_MAT, {bi, bi, 1, 1});
+    v->ao_b = t.add("decoder.mid.attn_1.proj_out.bias", PK_VEC, {bi});
+    v->mid2 = add_vres(v, "decoder.mid.block_2", bi, bi);
+    v->up.assign(c.num_levels, {});
+    v->ups_w.assign(c.num_levels, -1);
+    v->ups_b.assign(c.num_levels, -1);
+    char buf[96];
+    for (int lvl = c.num_levels - 1; lvl >= 0; --lvl) {
+        const int bo = c.ch * c.ch_mult[lvl];
+        if (bo % 64) return LD_ERR_SHAPE;
+        for (int b = 0; b <= c.num_res_blocks; ++b) {
+            snprintf(buf, sizeof buf, "decoder.up.%d.block.%d", lvl, b);
+            v->up[lvl].push_back(add_vres(v, buf, bi, bo));
+            bi = bo;
+        }
+        if (lvl != 0) {
+            snprintf(buf, sizeof buf, "decoder.up.%d.upsample.conv", lvl);
+            v->ups_w[lvl] = t.add(std::string(buf) + ".weight", PK_CONV3, {bi, bi, 3, 3});
+            v->ups_b[lvl] = t.add(std::string(buf) + ".bias", PK_VEC, {bi});
+        }
+    }
+    v->no_g = t.add("decoder.norm_out.weight", PK_VEC, {bi});
+    v->no_b = t.add("decoder.norm_out.bias", PK_VEC, {bi});
+    v->co_w = t.add("decoder.conv_out.weight", PK_CONV3, {c.out_ch, bi, 3, 3});
+    v->co_b = t.add("decoder.conv_out.bias", PK_VEC, {c.out_ch});
+    return t.finalize();
+}
+
+struct VRun {
+    ld_vae* v;
+    Exec ex;
+    int n;
+    half_t* P(int s) const { return v->pt.ptr(s); }
+
+    void conv(const half_t* x, int cin, int Hs, int Ws, int Hv, int Wv, int ksize, int wslot, int bslot, int cout, const half_t* R, half_t* out) {
+        GemmParams p;
+        p.conv = 1;
+        p.ksize = ksize;
+        p.A = x; p.C1 = cin;
+        p.Hs = Hs; p.Ws = Ws; p.Hv = Hv; p.Wv = Wv; p.Ho = Hv; p.Wo = Wv; p.stride = 1;
+        p.W = P(wslot); p.ldw = ksize * ksize * cin;
+        p.M = n * Hv * Wv; p.N = cout; p.K = ksize * ksize * cin;
+        p.bias_n = P(bslot);
+        p.R = R; p.ldr = cout;
+        p.C = out; p.ldc = cout;
+        ex.gemm(p);
+    }
+
+    // ResnetBlock.forward, LD.py:3560-3576 (GroupNorm eps 1e-6, swish)
+    half_t* resblock(const VResW& r, const half_t* x, int H, int W) {
+        Arena& ar = *ex.arena;
+        const size_t M = (size_t)n * H * W;
+        half_t* out = ar.halfs(M * r.cout);
+        const size_t mk = ar.mark();
+        half_t* g1 = ar.halfs(M * r.cin);
+        ex.groupnorm(x, r.cin, nullptr, 0, n, H * W, P(r.n1_g), P(r.n1_b), 1e-6f, 1, g1);
+        half_t* h1 = ar.halfs(M * r.cout);
+        conv(g1, r.cin, H, W, H, W, 3, r.c1_w, r.c1_b, r.cout, nullptr, h1);
+        half_t* g2 = r.cout <= r.cin ? g1 : ar.halfs(M * r.cout);
+        ex.groupnorm(h1, r.cout, nullptr, 0, n, H * W, P(r.n2_g), P(r.n2_b), 1e-6f, 1, g2);
+        const half_t* skip = x;
+        if (r.nin_w >= 0) {
+            half_t* sk = h1;   // h1 is dead after norm2
+            conv(x, r.cin, H, W, H, W, 1, r.nin_w, r.nin_b, r.cout, nullptr, sk);
+            skip = sk;
+        }
+        conv(g2, r.cout, H, W, H, W, 3, r.c2_w, r.c2_b, r.cout, skip, out);
+        ar.release(mk);
+        return out;
+    }
+
+    // AttnBlock.forward, LD.py:3630-3642
+    half_t* attn(const half_t* x, int H, int W) {
+        Arena& ar = *ex.arena;
+        const int C = v->block_in0, L = H * W;
+        const size_t M = (size_t)n * L;
+        half_t* out = ar.halfs(M * C);
+        const size_t mk = ar.mark();
+        half_t* g = ar.halfs(M * C);
+        ex.groupnorm(x, C, nullptr, 0, n, L, P(v->an_g), P(v->an_b), 1e-6f, 0, g);
+        half_t* qk = ar.halfs(M * 2 * C);
+        {
+            GemmParams p;
+            p.A = g; p.lda = C; p.W = P(v->aq_w); p.ldw = C;
+            p.M = (int)M; p.N = 2 * C; p.K = C; p.bias_n = P(v->aq_b);
+            p.C = qk; p.ldc = 2 * C;
+            ex.gemm(p);
+        }
+        half_t* vt = ar.halfs(M * C);
+        {   // V^T[b] = Wv · g_b^T + bv (bias along rows)
+            GemmParams p;
+            p.A = P(v->av_w); p.lda = C; p.sA = 0;
+            p.W = g; p.ldw = C; p.sW = (long long)L * C;
+            p.M = C; p.N = L; p.K = C; p.batch = n;
+            p.bias_m = P(v->av_b);
+            p.C = vt; p.ldc = L; p.sC = (long long)C * L;
+            ex.gemm(p);
+        }
+        half_t* s = ar.halfs((size_t)n * L * L);
+        {   // S_b = Q_b K_b^T / sqrt(C)
+            GemmParams p;
+            p.A = qk; p.lda = 2 * C; p.sA = (long long)L * 2 * C;
+            p.W = qk + C; p.ldw = 2 * C; p.sW = (long long)L * 2 * C;
+            p.M = L; p.N = L; p.K = C; p.batch = n;
+            p.alpha = 1.0f / sqrtf((float)C);
+            p.C = s; p.ldc = L; p.sC = (long long)L * L;
+            ex.gemm(p);
+        }
+        ex.launches += 1;
+        if (!ex.dry && ex.status == LD_OK) ex.note(softmax_rows_launch(s, n * L, L, L, ex.stream));
+        half_t* o = g;   // reuse
+        {   // O_b = P_b V_b  (W operand = V^T [C][L])
+            GemmParams p;
+            p.A = s; p.lda = L; p.sA = (long long)L * L;
+            p.W = vt; p.ldw = L; p.sW = (long long)C * L;
+            p.M = L; p.N = C; p.K = L; p.batch = n;
+            p.C = o; p.ldc = C; p.sC = (long long)L * C;
+            ex.gemm(p);
+        }
+        {
+            GemmParams p;
+            p.A = o; p.lda = C; p.W = P(v->ao_w); p.ldw = C;
+            p.M = (int)M; p.N = C; p.K = C; p.bias_n = P(v->ao_b);
+            p.R = x; p.ldr = C;
+            p.C = out; p.ldc = C;
+            ex.gemm(p);
+        }
+        ar.release(mk);
+        return out;
+    }
+};
+
+int run_decode(ld_vae* v, bool dry, const float* z, float* out, int b, int h, int w, hipStream_t stream, size_t* dry_peak = nullptr) {
+    VRun R;
+    R.v = v;
+    R.n = b;
+    Exec& ex = R.ex;
+    ex.stream = stream;
+    ex.dry = dry;
+    Arena plan;
+    ex.arena = dry ? &plan : &v->arena;
+    ex.splitk_ws = v->splitk_ws;
+    ex.splitk_bytes = v->splitk_bytes;
+    Arena& ar = *ex.arena;
+    ar.release(0);
+    const ld_vae_config& c = v->cfg;
+    int H = h, W = w;
+    int C = v->block_in0;
+    half_t* f = ar.halfs((size_t)b * H * W * C);
+    {
+        SmallConvInArgs a;
+        a.x = z; a.pre_w = v->pt.ptr(v->pq_w); a.pre_b = v->pt.ptr(v->pq_b);
+        a.w = v->pt.ptr(v->cin_w); a.b = v->pt.ptr(v->cin_b); a.y = f;
+        a.N = b; a.Cin = c.z_channels; a.H = H; a.W = W; a.Cout = C;
+        ex.launches += 1;
+        ex.flops += 2.0 * b * H * W * C * 9.0 * c.z_channels;
+        if (!dry) ex.note(small_conv_in_launch(a, stream));
+    }
+    f = R.resblock(v->mid1, f, H, W);
+    f = R.attn(f, H, W);
+    f = R.resblock(v->mid2, f, H, W);
+    for (int lvl = c.num_levels - 1; lvl >= 0; --lvl) {
+        for (const VResW& r : v->up[lvl]) {
+            f = R.resblock(r, f, H, W);
+            C = r.cout;
+        }
+        if (lvl != 0) {   // Upsample: nearest 2x then conv (LD.py:3498-3511), fused into the conv's loader
+            half_t* o = ar.halfs((size_t)b * 4 * H * W * C);
+            R.conv(f, C, H, W, 2 * H, 2 * W, 3, v->ups_w[lvl], v->ups_b[lvl], C, nullptr, o);
+            f = o;
+            H *= 2;
+            W *= 2;
+        }
+    }
+    {
+        half_t* g = ar.halfs((size_t)b * H * W * C);
+        ex.groupnorm(f, C, nullptr, 0, b, H * W, v->pt.ptr(v->no_g), v->pt.ptr(v->no_b), 1e-6f, 1, g);
+        SmallConvOutArgs a;
+        a.x = g; a.w = v->pt.ptr(v->co_w); a.b = v->pt.ptr(v->co_b);
+        a.N = b; a.H = H; a.W = W; a.Cin = C; a.Cout = c.out_ch; a.mode = 1; a.out = out;
+        ex.launches += 1;
+        ex.flops += 2.0 * b * H * W * C * 9.0 * c.out_ch;
+        if (!dry) ex.note(small_conv_out_launch(a, stream));
+    }
+    v->last_launches = ex.launches;
+    v->last_flops = ex.flops;
+    if (dry_peak) *dry_peak = ar.peak;
+    return ex.status;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ld_vae_create(const ld_vae_config* cfg, ld_vae** out) {
+    if (cfg == nullptr || out == nullptr) return LD_ERR_ARG;
+    ld_vae* v = new ld_vae();
+    v->cfg = *cfg;
+    const int st = build(v);
+    if (st != LD_OK) {
+        v->pt.destroy();
+        delete v;
+        return st;
+    }
+    *out = v;
+    return LD_OK;
+}
+
+void ld_vae_destroy(ld_vae* v) {
+    if (v == nullptr) return;
+    v->pt.destroy();
+    if (v->ws_base) (void)hipFree(v->ws_base);
+    delete v;
+}
+
+int ld_vae_param_count(const ld_vae* v) { return v ? (int)v->pt.slots.size() : 0; }
+
+int ld_vae_param_info(const ld_vae* v, int i, const char** name, int* ndim, int64_t shape[4]) {
+    if (v == nullptr || i < 0 || i >= (int)v->pt.slots.size()) return LD_ERR_ARG;
+    const ParamSlot& s = v->pt.slots[i];
+    if (name) *name = s.name.c_str();
+    if (ndim) *ndim = s.ndim;
+    if (shape)
+        for (int k = 0; k < 4; ++k) shape[k] = s.shape[k];
+    return LD_OK;
+}
+
+int ld_vae_load_param(ld_vae* v, const char* name, const void* src, int dtype, void* stream) {
+    if (v == nullptr || name == nullptr) return LD_ERR_ARG;
+    return v->pt.load(name, src, dtype, (hipStream_t)stream);
+}
+
+size_t ld_vae_workspace_bytes(const ld_vae* v) { return v ? v->ws_bytes : 0; }
+
+int ld_vae_reserve(ld_vae* v, int max_b, int max_h, int max_w) {
+    if (v == nullptr || max_b < 1 || max_h < 1 || max_w < 1) return LD_ERR_ARG;
+    if (v->ws_base) {
+        (void)hipFree(v->ws_base);
+        v->ws_base = nullptr;
+    }
+    v->arena = Arena();
+    v->plan_b = v->plan_h = v->plan_w = 0;
+    size_t peak = 0;
+    const int st = run_decode(v, true, nullptr, nullptr, max_b, max_h, max_w, nullptr, &peak);
+    if (st != LD_OK) return st;
+    const size_t act = (peak + 4095) / 4096 * 4096;
+    v->splitk_bytes = (size_t)64 << 20;
+    v->ws_bytes = act + v->splitk_bytes + 4096;
+    if (hipMalloc((void**)&v->ws_base, v->ws_bytes) != hipSuccess) {
+        v->ws_base = nullptr;
+        return LD_ERR_HIP;
+    }
+    v->arena.base = v->ws_base;
+    v->arena.cap = act;
+    v->splitk_ws = reinterpret_cast<float*>(v->ws_base + act);
+    return LD_OK;
+}
+
+int ld_vae_decode(ld_vae* v, const float* z, float* out, int b, int h, int w, void* stream) {
+    if (v == nullptr || z == nullptr || out == nullptr) return LD_ERR_ARG;
+    if (v->ws_base == nullptr || !v->pt.all_loaded()) return LD_ERR_STATE;
+    if (b < 1 || h < 1 || w < 1 || ((h * w) & 7)) return LD_ERR_SHAPE;
+    if (b != v->plan_b || h != v->plan_h || w != v->plan_w) {
+        size_t peak = 0;
+        const int st = run_decode(v, true, nullptr, nullptr, b, h, w, nullptr, &peak);
+        if (st != LD_OK) return st;
+        if (peak > v->arena.cap) return LD_ERR_SHAPE;
+        v->plan_b = b;
+        v->plan_h = h;
+        v->plan_w = w;
+    }
+    return run_decode(v, false, z, out, b, h, w, (hipStream_t)stream);
+}
+
+int ld_vae_last_launches(const ld_vae* v) { return v ? v->last_launches : 0; }
+double ld_vae_last_flops(const ld_vae* v) { return v ? v->last_flops : 0.0; }
+
+}  // extern "C"

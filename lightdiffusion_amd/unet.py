@@ -1,0 +1,208 @@
+"""MI355X UNet / VAE objects that sit behind the reference's plugin seams.
+
+* `MI355XUNet` satisfies the `model_function_wrapper` contract (LD.py:2558-2567, installed with
+  `ModelPatcher.set_model_unet_function_wrapper`, LD.py:3277): `fn(apply_model, {"input", "timestep", "c",
+  "cond_or_uncond"}) -> denoised fp32`, plus `.to(device)` (LD.py:3286-3291) — the same contract the reference's
+  stable-fast integration implements (`StableFastPatch`, LD.py:9902-9933).
+* `MI355XVAE.decode` mirrors `VAE.decode` (LD.py:6357-6381): [B,4,h,w] -> [B,8h,8w,3] fp32 in [0,1].
+
+Both are thin: they own a C handle, feed it device pointers and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, Optional, Union
+
+import torch
+
+from . import weights as W
+from ._lib import F16, F32, UNetConfig, VAEConfig, check, lib
+
+WeightSource = Union[Dict[str, torch.Tensor], Callable[[str, tuple], torch.Tensor]]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _load_params(handle, count_fn, info_fn, load_fn, src: WeightSource, device, prefixes=("",)):
+    name, ndim, shape = C.c_char_p(), C.c_int(), (C.c_int64 * 4)()
+    for i in range(count_fn(handle)):
+        check(info_fn(handle, i, C.byref(name), C.byref(ndim), shape), "param_info")
+        key = name.value.decode()
+        shp = tuple(int(shape[k]) for k in range(ndim.value))
+        if callable(src):
+            t = src(key, shp)
+        else:
+            t = None
+            for p in prefixes:
+                if p + key in src:
+                    t = src[p + key]
+                    break
+            if t is None:
+                raise KeyError(f"checkpoint is missing '{key}'")
+        if tuple(t.shape) != shp:
+            raise ValueError(f"'{key}': expected shape {shp}, got {tuple(t.shape)}")
+        if t.dtype not in (torch.float16, torch.float32):
+            t = t.float()
+        t = t.to(device).contiguous()
+        check(load_fn(handle, key.encode(), t.data_ptr(), F32 if t.dtype == torch.float32 else F16, _stream()), f"load_param({key})")
+    torch.cuda.synchronize(device)
+
+
+class MI355XUNet:
+    """SD1.x UNet resident on one MI355X.  `cfg` as in `weights.sd15_unet_config()`."""
+
+    def __init__(self, cfg: dict, weights: WeightSource, device="cuda:0", max_batch: int = 2, max_hw=(64, 64), max_tokens: int = 77):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        c = UNetConfig()
+        c.in_channels, c.out_channels, c.model_channels = cfg["in_channels"], cfg["out_channels"], cfg["model_channels"]
+        c.num_levels = len(cfg["channel_mult"])
+        for i, v in enumerate(cfg["channel_mult"]):
+            c.channel_mult[i] = v
+        for i, v in enumerate(cfg["num_res_blocks"]):
+            c.num_res_blocks[i] = v
+        for i, v in enumerate(cfg["transformer_depth"]):
+            c.transformer_depth[i] = v
+        for i, v in enumerate(cfg["transformer_depth_output"]):
+            c.transformer_depth_output[i] = v
+        c.transformer_depth_middle = cfg["transformer_depth_middle"]
+        c.context_dim, c.num_heads = cfg["context_dim"], cfg["num_heads"]
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().ld_unet_create(C.byref(c), C.byref(self._h)), "ld_unet_create")
+            _load_params(self._h, lib().ld_unet_param_count, lib().ld_unet_param_info, lib().ld_unet_load_param, weights,
+                         self.device, ("", "model.diffusion_model."))
+            check(lib().ld_unet_reserve(self._h, max_batch, max_hw[0], max_hw[1], max_tokens), "ld_unet_reserve")
+        self._ctx_key = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().ld_unet_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    # -- sizes
+    @property
+    def weight_bytes(self) -> int:
+        return lib().ld_unet_weight_bytes(self._h)
+
+    @property
+    def workspace_bytes(self) -> int:
+        return lib().ld_unet_workspace_bytes(self._h)
+
+    @property
+    def last_launches(self) -> int:
+        return lib().ld_unet_last_launches(self._h)
+
+    @property
+    def last_flops(self) -> float:
+        return lib().ld_unet_last_flops(self._h)
+
+    # -- hot path
+    def set_context(self, ctx: torch.Tensor) -> None:
+        """ctx [N, T, context_dim], batch order exactly as the reference batches it: [uncond..., cond...]."""
+        ctx = ctx.to(self.device)
+        if ctx.dtype not in (torch.float16, torch.float32):
+            ctx = ctx.float()
+        ctx = ctx.contiguous()
+        with torch.cuda.device(self.device):
+            check(lib().ld_unet_set_context(self._h, ctx.data_ptr(), F32 if ctx.dtype == torch.float32 else F16, ctx.shape[0],
+                                            ctx.shape[1], _stream()), "ld_unet_set_context")
+        self._ctx_key = None
+
+    def forward(self, x: torch.Tensor, sigma: torch.Tensor, out: Optional[torch.Tensor] = None, eps_only: bool = False) -> torch.Tensor:
+        """x [N,4,h,w] fp32 (device), sigma [N] fp32 (device) -> denoised [N,4,h,w] fp32 = x - eps*sigma."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        assert sigma.is_cuda and sigma.dtype == torch.float32 and sigma.is_contiguous()
+        if out is None:
+            out = torch.empty_like(x)
+        n, _, h, w = x.shape
+        with torch.cuda.device(self.device):
+            check(lib().ld_unet_forward(self._h, x.data_ptr(), sigma.data_ptr(), out.data_ptr(), n, h, w, int(eps_only), _stream()),
+                  "ld_unet_forward")
+        return out
+
+    # -- the reference's plugin seam
+    def __call__(self, apply_model, params: dict) -> torch.Tensor:
+        x = params["input"]
+        sigma = params["timestep"]
+        ctx = params["c"]["c_crossattn"]
+        x = x.to(self.device, torch.float32).contiguous()
+        sigma = sigma.to(self.device, torch.float32).contiguous()
+        # the reference re-concatenates the context every step (cond_cat, LD.py:2471-2489): re-project only when it changed
+        key = (ctx.data_ptr(), tuple(ctx.shape), ctx._version)
+        if self._ctx_key is None or key != self._ctx_key[0] and not torch.equal(ctx.to(self.device), self._ctx_key[1]):
+            self.set_context(ctx)
+            self._ctx_key = (key, ctx.to(self.device).clone())
+        return self.forward(x, sigma)
+
+    def to(self, device):
+        return self
+
+
+class MI355XVAE:
+    """KL-VAE decoder resident on one MI355X.  `cfg` as in `weights.sd15_vae_config()`."""
+
+    downscale_ratio = 8
+    latent_channels = 4
+
+    def __init__(self, cfg: dict, weights: WeightSource, device="cuda:0", max_batch: int = 1, max_hw=(64, 64)):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        c = VAEConfig()
+        c.z_channels, c.ch, c.num_levels = cfg["z_channels"], cfg["ch"], len(cfg["ch_mult"])
+        for i, v in enumerate(cfg["ch_mult"]):
+            c.ch_mult[i] = v
+        c.num_res_blocks, c.out_ch = cfg["num_res_blocks"], cfg["out_ch"]
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().ld_vae_create(C.byref(c), C.byref(self._h)), "ld_vae_create")
+            _load_params(self._h, lib().ld_vae_param_count, lib().ld_vae_param_info, lib().ld_vae_load_param, weights,
+                         self.device, ("", "first_stage_model."))
+            check(lib().ld_vae_reserve(self._h, max_batch, max_hw[0], max_hw[1]), "ld_vae_reserve")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().ld_vae_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self) -> int:
+        return lib().ld_vae_workspace_bytes(self._h)
+
+    @property
+    def last_flops(self) -> float:
+        return lib().ld_vae_last_flops(self._h)
+
+    @property
+    def last_launches(self) -> int:
+        return lib().ld_vae_last_launches(self._h)
+
+    def decode_device(self, z: torch.Tensor) -> torch.Tensor:
+        z = z.to(self.device, torch.float32).contiguous()
+        b, _, h, w = z.shape
+        out = torch.empty(b, 8 * h, 8 * w, self.cfg["out_ch"], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().ld_vae_decode(self._h, z.data_ptr(), out.data_ptr(), b, h, w, _stream()), "ld_vae_decode")
+        return out
+
+    def decode(self, samples_in: torch.Tensor) -> torch.Tensor:
+        """VAE.decode (LD.py:6357-6381): returns [B, 8h, 8w, 3] fp32 in [0,1] on the CPU (`intermediate_device`)."""
+        return self.decode_device(samples_in).cpu()
+
+
+def synthetic_unet(cfg: Optional[dict] = None, seed: int = 0, **kw) -> MI355XUNet:
+    cfg = cfg or W.sd15_unet_config()
+    return MI355XUNet(cfg, lambda name, shape: W.synth_tensor(name, shape, seed), **kw)
+
+
+def synthetic_vae(cfg: Optional[dict] = None, seed: int = 0, **kw) -> MI355XVAE:
+    cfg = cfg or W.sd15_vae_config()
+    return MI355XVAE(cfg, lambda name, shape: W.synth_tensor(name, shape, seed), **kw)

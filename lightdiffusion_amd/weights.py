@@ -38,7 +38,7 @@ def sd15_vae_config() -> dict:
 
 
 def tiny_vae_config() -> dict:
-    return dict(z_channels=4, ch=32, ch_mult=[1, 2, 4, 4], num_res_blocks=2, out_ch=3)
+    return dict(z_channels=4, ch=64, ch_mult=[1, 2, 4, 4], num_res_blocks=2, out_ch=3)
 
 
 def sd15_clip_config() -> dict:

@@ -110,8 +110,8 @@ def g_blocks():
     q, k, v = rnd((2, 40, 80), 19), rnd((2, 77, 80), 20), rnd((2, 77, 80), 21)
     save("attention", q=q, k=k, v=v, y_h2=ref.attention_pytorch(q, k, v, 2), y_h10=ref.attention_pytorch(q, k, v, 10))
     # VAE blocks
-    m = fill(ref.ResnetBlock(in_channels=64, out_channels=32, dropout=0.0), "blk.vres.")
-    x = rnd((1, 64, 10, 12), 22)
+    m = fill(ref.ResnetBlock(in_channels=128, out_channels=64, dropout=0.0), "blk.vres.")
+    x = rnd((1, 128, 10, 12), 22)
     save("block_vae_res", x=x, y=m(x, None))
     m = fill(ref.AttnBlock(64), "blk.vattn.")
     x = rnd((1, 64, 8, 8), 23)

@@ -1,0 +1,207 @@
+"""GPU parity: every hand-written HIP operator, called through the C ABI (lightdiffusion_amd.ops), against the
+CPU oracle / a plain torch fp32 CPU evaluation of the same op on the same fp16-rounded inputs.
+Tolerances (fp16 storage, fp32 accumulate): rel-L2 <= 2e-3 per op unless a test states otherwise."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_l2
+from lightdiffusion_amd import weights as W
+from oracle import sd15_ref as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-3
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from lightdiffusion_amd import ops as o
+    from lightdiffusion_amd._lib import lib
+    lib()
+    return o
+
+
+def r16(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).half()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K,bias,res,act", [
+    (256, 320, 320, True, False, "none"), (200, 320, 1280, True, True, "none"), (77, 192, 72, False, False, "none"),
+    (4096, 640, 640, True, True, "none"), (2, 1280, 320, True, False, "silu"), (128, 1280, 11520, True, True, "none"),
+    (1024, 960, 320, False, False, "none"), (16, 4032, 256, True, False, "none")])
+def test_linear(ops, M, N, K, bias, res, act):
+    x, w = r16((M, K), 1), r16((N, K), 2, 1 / math.sqrt(K))
+    b = r16((N,), 3, 0.1) if bias else None
+    r = r16((M, N), 4) if res else None
+    ref = F.linear(x.float(), w.float(), None if b is None else b.float())
+    if act == "silu":
+        ref = F.silu(ref)
+    if r is not None:
+        ref = ref + r.float()
+    y = ops.linear(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), None if r is None else r.to(DEV), act=act)
+    assert rel_l2(y.float().cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("M,C", [(300, 64), (4096, 320), (64, 1280)])
+def test_geglu(ops, M, C):
+    x, w, b = r16((M, C), 5), r16((8 * C, C), 6, 1 / math.sqrt(C)), r16((8 * C,), 7, 0.1)
+    a, g = F.linear(x.float(), w.float(), b.float()).chunk(2, dim=-1)
+    y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act="geglu")
+    assert rel_l2(y.float().cpu(), a * F.gelu(g)) < TOL
+
+
+def test_geglu_golden(ops):
+    g = load_golden("block_geglu")
+    w, b = W.synth_tensor("blk.geglu.proj.weight", (512, 64)).half(), W.synth_tensor("blk.geglu.proj.bias", (512,)).half()
+    y = ops.linear(g["x"].half().to(DEV), w.to(DEV), b.to(DEV), act="geglu")
+    assert rel_l2(y.float().cpu(), g["y"]) < 3e-3
+
+
+@pytest.mark.parametrize("n,h,w,c1,c2,cout,stride,out_hw,rv,res", [
+    (2, 12, 10, 64, 0, 128, 1, None, True, False), (2, 12, 10, 64, 0, 64, 2, None, False, False),
+    (1, 16, 16, 128, 64, 64, 1, None, False, True), (2, 6, 5, 64, 0, 64, 1, (12, 10), False, False),
+    (2, 6, 5, 64, 0, 64, 1, (11, 9), False, False), (2, 32, 32, 320, 0, 320, 1, None, True, True),
+    (2, 8, 8, 1280, 1280, 1280, 1, None, True, False), (1, 9, 7, 64, 64, 192, 2, None, False, False)])
+def test_conv3x3(ops, n, h, w, c1, c2, cout, stride, out_hw, rv, res):
+    x1 = r16((n, c1, h, w), 11)
+    x2 = r16((n, c2, h, w), 12) if c2 else None
+    cin = c1 + c2
+    wt, b = r16((cout, cin, 3, 3), 13, 1 / math.sqrt(9 * cin)), r16((cout,), 14, 0.1)
+    xin = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], 1)
+    if out_hw is not None:
+        xin = F.interpolate(xin, size=out_hw, mode="nearest")
+    ref = F.conv2d(xin, wt.float(), b.float(), stride=stride, padding=1)
+    rowvec = r16((n, cout), 15) if rv else None
+    if rv:
+        ref = ref + rowvec.float()[:, :, None, None]
+    r = r16(tuple(ref.shape), 16) if res else None
+    if res:
+        ref = ref + r.float()
+    wp = ops.repack_conv_weight(wt.to(DEV))
+    y = ops.conv2d(nhwc(x1).to(DEV), wp, b.to(DEV), 3, stride, None if x2 is None else nhwc(x2).to(DEV), out_hw,
+                   None if rowvec is None else rowvec.to(DEV), None if r is None else nhwc(r).to(DEV))
+    assert rel_l2(nchw(y.float().cpu()), ref) < TOL
+
+
+def test_conv1x1_concat(ops):
+    x1, x2 = r16((2, 128, 9, 8), 21), r16((2, 64, 9, 8), 22)
+    wt, b = r16((320, 192, 1, 1), 23, 1 / math.sqrt(192)), r16((320,), 24, 0.1)
+    ref = F.conv2d(torch.cat([x1.float(), x2.float()], 1), wt.float(), b.float())
+    y = ops.conv2d(nhwc(x1).to(DEV), ops.repack_conv_weight(wt.to(DEV)), b.to(DEV), 1, 1, nhwc(x2).to(DEV))
+    assert rel_l2(nchw(y.float().cpu()), ref) < TOL
+
+
+def test_block_goldens_via_ops(ops):
+    """ResBlock1 / Downsample1 / Upsample1 of the reference (goldens) rebuilt from the operator seam."""
+    for tag, cin, cout in (("res_skip", 64, 128), ("res_id", 64, 64)):
+        g = load_golden("block_" + tag)
+        P = lambda k, s: W.synth_tensor(f"blk.{tag}.{k}", s).half().to(DEV)
+        x = nhwc(g["x"].half()).to(DEV)
+        emb = F.linear(F.silu(g["emb"]), W.synth_tensor(f"blk.{tag}.emb_layers.1.weight", (cout, 256)),
+                       W.synth_tensor(f"blk.{tag}.emb_layers.1.bias", (cout,))).half().to(DEV)
+        h = ops.group_norm(x, P("in_layers.0.weight", (cin,)), P("in_layers.0.bias", (cin,)), 1e-5, True)
+        h = ops.conv2d(h, ops.repack_conv_weight(P("in_layers.2.weight", (cout, cin, 3, 3))), P("in_layers.2.bias", (cout,)), rowvec=emb)
+        h = ops.group_norm(h, P("out_layers.0.weight", (cout,)), P("out_layers.0.bias", (cout,)), 1e-5, True)
+        skip = x
+        if cin != cout:
+            skip = ops.conv2d(x, ops.repack_conv_weight(P("skip_connection.weight", (cout, cin, 1, 1))), P("skip_connection.bias", (cout,)), 1)
+        y = ops.conv2d(h, ops.repack_conv_weight(P("out_layers.3.weight", (cout, cout, 3, 3))), P("out_layers.3.bias", (cout,)), residual=skip)
+        assert rel_l2(nchw(y.float().cpu()), g["y"]) < 3e-3
+    g = load_golden("block_down")
+    wt = ops.repack_conv_weight(W.synth_tensor("blk.down.op.weight", (64, 64, 3, 3)).half().to(DEV))
+    y = ops.conv2d(nhwc(g["x"].half()).to(DEV), wt, W.synth_tensor("blk.down.op.bias", (64,)).half().to(DEV), stride=2)
+    assert rel_l2(nchw(y.float().cpu()), g["y"]) < TOL
+    g = load_golden("block_up")
+    wt = ops.repack_conv_weight(W.synth_tensor("blk.up.conv.weight", (64, 64, 3, 3)).half().to(DEV))
+    bb = W.synth_tensor("blk.up.conv.bias", (64,)).half().to(DEV)
+    x = nhwc(g["x"].half()).to(DEV)
+    assert rel_l2(nchw(ops.conv2d(x, wt, bb, out_hw=(12, 10)).float().cpu()), g["y"]) < TOL
+    assert rel_l2(nchw(ops.conv2d(x, wt, bb, out_hw=(11, 9)).float().cpu()), g["y_odd"]) < TOL
+
+
+@pytest.mark.parametrize("n,hw,c1,c2,eps,silu", [
+    (2, 120, 64, 0, 1e-5, True), (2, 4096, 320, 0, 1e-6, False), (1, 64, 64, 32, 1e-5, True), (2, 256, 640, 320, 1e-5, True),
+    (2, 64, 1280, 1280, 1e-5, True), (1, 16384, 128, 0, 1e-6, True), (3, 77, 96, 0, 1e-5, False)])
+def test_groupnorm(ops, n, hw, c1, c2, eps, silu):
+    x1 = r16((n, hw, c1), 31, 2.0) + 0.5
+    x2 = (r16((n, hw, c2), 32) - 1.0) if c2 else None
+    c = c1 + c2
+    ga, be = (1 + 0.1 * r16((c,), 33).float()).half(), r16((c,), 34, 0.1)
+    xin = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], -1)
+    ref = F.group_norm(xin.transpose(1, 2), 32, ga.float(), be.float(), eps).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    y = ops.group_norm(x1.to(DEV), ga.to(DEV), be.to(DEV), eps, silu, None if x2 is None else x2.to(DEV))
+    assert rel_l2(y.float().cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("rows,c", [(5, 64), (4096, 320), (130, 1280), (7, 2048)])
+def test_layernorm(ops, rows, c):
+    x, ga, be = r16((rows, c), 41, 3.0), (1 + 0.1 * r16((c,), 42).float()).half(), r16((c,), 43, 0.1)
+    y = ops.layer_norm(x.to(DEV), ga.to(DEV), be.to(DEV), 1e-5)
+    assert rel_l2(y.float().cpu(), F.layer_norm(x.float(), (c,), ga.float(), be.float(), 1e-5)) < TOL
+
+
+@pytest.mark.parametrize("b,heads,lq,lk,d", [
+    (2, 8, 256, 256, 40), (1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160), (2, 8, 64, 64, 160),
+    (2, 8, 100, 77, 40), (2, 8, 1024, 77, 80), (1, 8, 64, 77, 160), (2, 8, 192, 192, 8), (1, 4, 130, 200, 32), (2, 2, 70, 154, 64)])
+def test_attention(ops, b, heads, lq, lk, d):
+    c = heads * d
+    q, k, v = r16((b, lq, c), 51), r16((b, lk, c), 52), r16((b, lk, c), 53)
+    y = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    assert rel_l2(y.float().cpu(), O.attention(q.float(), k.float(), v.float(), heads)) < TOL
+
+
+def test_attention_softmax_rescale_branch(ops):
+    """Force the running max to jump late (guide rule 26): one key far larger than the rest, placed in the last tile."""
+    b, heads, l, d = 1, 2, 256, 40
+    q, k, v = r16((b, l, heads * d), 54), r16((b, l, heads * d), 55), r16((b, l, heads * d), 56)
+    k[:, 200] = q[:, 3] * 4.0
+    k[:, 70] = q[:, 9] * 3.0
+    y = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    assert rel_l2(y.float().cpu(), O.attention(q.float(), k.float(), v.float(), heads)) < TOL
+
+
+def test_attention_golden(ops):
+    g = load_golden("attention")
+    for heads, key in ((2, "y_h2"), (10, "y_h10")):
+        y = ops.attention(g["q"].half().to(DEV), g["k"].half().to(DEV), g["v"].half().to(DEV), heads)
+        assert rel_l2(y.float().cpu(), g[key]) < 3e-3
+
+
+def test_softmax_rows(ops):
+    s = r16((300, 4096), 61, 4.0)
+    y = ops.softmax_rows_(s.to(DEV).clone())
+    assert rel_l2(y.float().cpu(), torch.softmax(s.float(), -1)) < TOL
+
+
+def test_timestep_embed_golden(ops):
+    g = load_golden("schedules")
+    ls = g["log_sigmas"].to(DEV)
+    emb, t = ops.timestep_embed(g["probe_sigma"].to(DEV), ls, 320)
+    assert torch.equal(t.cpu().long(), g["probe_t"])
+    emb, t = ops.timestep_embed(g["sigmas"][[0, 1, 37, 999]].to(DEV), ls, 320)
+    assert torch.equal(t.cpu(), g["temb_t"])
+    assert float((emb.float().cpu() - g["temb"]).abs().max()) < 2e-3      # fp16 rounding of values in [-1, 1]
+
+
+def test_sampler_elementwise(ops):
+    den2, x = torch.randn(4, 4, 8, 8), torch.randn(2, 4, 8, 8)
+    y, z = torch.randn(2, 4, 8, 8), torch.randn(2, 4, 8, 8)
+    out = ops.cfg_combine(den2.to(DEV), 7.5).cpu()
+    u, c = den2.chunk(2)
+    assert torch.allclose(out, u + (c - u) * 7.5, atol=1e-5)
+    xx = ops.axpby_(x.to(DEV).clone(), 0.5, y.to(DEV), -2.0, z.to(DEV), 0.25).cpu()
+    assert torch.allclose(xx, 0.5 * x - 2.0 * y + 0.25 * z, atol=1e-5)

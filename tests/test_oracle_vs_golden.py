@@ -94,8 +94,8 @@ def test_spatial_transformer_attention_geglu():
 
 def test_vae_blocks():
     g = load_golden("block_vae_res")
-    shp = {"norm1.weight": (64,), "norm1.bias": (64,), "conv1.weight": (32, 64, 3, 3), "conv1.bias": (32,), "norm2.weight": (32,),
-           "norm2.bias": (32,), "conv2.weight": (32, 32, 3, 3), "conv2.bias": (32,), "nin_shortcut.weight": (32, 64, 1, 1), "nin_shortcut.bias": (32,)}
+    shp = {"norm1.weight": (128,), "norm1.bias": (128,), "conv1.weight": (64, 128, 3, 3), "conv1.bias": (64,), "norm2.weight": (64,),
+           "norm2.bias": (64,), "conv2.weight": (64, 64, 3, 3), "conv2.bias": (64,), "nin_shortcut.weight": (64, 128, 1, 1), "nin_shortcut.bias": (64,)}
     sd = {"v." + k: v for k, v in sdict(shp, "blk.vres.").items()}
     assert rel_l2(O.vae_resblock(g["x"], sd, "v"), g["y"]) < 2e-6
     g = load_golden("block_vae_attn")
