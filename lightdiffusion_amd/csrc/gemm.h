@@ -19,6 +19,7 @@ struct GemmParams {
     const half_t* W = nullptr;
     int ldw = 0;
     int M = 0, N = 0, K = 0;
+    int n_valid = 0;             // rows of W that exist (0 = N); rows n_valid..N-1 read as zeros (padded outputs)
     // ---- batching over blockIdx.z (element strides)
     int batch = 1;
     long long sA = 0, sW = 0, sC = 0, sR = 0;

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
         for (int i = 0; i < B_IT; ++i) {
             const int q = tid + i * NT;
             const int row = q >> 3;
-            const bool ok = (q < BN * 8) && (n0 + row < p.N) && kok;
+            const bool ok = (q < BN * 8) && (n0 + row < p.n_valid) && kok;
             rb[i] = ok ? ld16(Wb + (long long)(n0 + row) * p.ldw + kc) : zero16();
         }
     };
@@ -346,6 +346,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (p.act == 2 && (p.bias_n == nullptr || (p.N & 15))) return LD_ERR_ARG;
     if (p.R != nullptr && (p.ldr & 7)) return LD_ERR_SHAPE;
 
+    if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     int bn = p.bn ? p.bn : gemm_pick_bn(p.N);
     if (bn != 128 && bn != 160) return LD_ERR_ARG;
     if (p.act == 2 && (p.N % bn)) return LD_ERR_SHAPE;

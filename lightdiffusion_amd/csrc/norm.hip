@@ -30,11 +30,11 @@ __device__ __forceinline__ const half_t* gn_src(const GnArgs& a, int n, int pix,
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
+    // per-(pixel-lane, channel) partial sums, each slot written by exactly one thread; reduced in a fixed order
+    // (no float atomics: bitwise reproducible run to run)
     __shared__ float csum[4096], csq[4096];
     const int C = a.C1 + a.C2, CH = C >> 3, cpg = C / 32;
     const int n = blockIdx.y, pc = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < C; i += GN_THREADS) csum[i] = csq[i] = 0.f;
-    __syncthreads();
     const int rows_par = CH >= GN_THREADS ? 1 : GN_THREADS / CH;
     const int p_begin = pc * a.ppb, p_end = min(a.HW, p_begin + a.ppb);
 #pragma unroll
@@ -64,20 +64,30 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            atomicAdd(&csum[cc * 8 + j], s[j]);
-            atomicAdd(&csq[cc * 8 + j], ss[j]);
+            csum[prow * C + cc * 8 + j] = s[j];      // rows_par * C <= 4096
+            csq[prow * C + cc * 8 + j] = ss[j];
         }
     }
     __syncthreads();
-    if (tid < 32) {
+    {
+        const int g = tid >> 3, sub = tid & 7;
+        const int cnt = rows_par * cpg;
         float s = 0.f, ss = 0.f;
-        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-            s += csum[c];
-            ss += csq[c];
+        for (int i = sub; i < cnt; i += 8) {
+            const int pr = i / cpg, c = g * cpg + (i - pr * cpg);
+            s += csum[pr * C + c];
+            ss += csq[pr * C + c];
         }
-        float* o = a.partial + (((long long)n * a.P + pc) * 32 + tid) * 2;
-        o[0] = s;
-        o[1] = ss;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            ss += __shfl_xor(ss, o, 64);
+        }
+        if (sub == 0) {
+            float* o = a.partial + (((long long)n * a.P + pc) * 32 + g) * 2;
+            o[0] = s;
+            o[1] = ss;
+        }
     }
 }
 

@@ -287,13 +287,14 @@ struct Run {
         ex.layernorm(t, P(s.ln1_g), P(s.ln1_b), nrm, M, C);
         half_t* qk = ar.halfs((size_t)M * 2 * C);
         linear(nrm, C, s.q1_w, -1, nullptr, qk, M, 2 * C, C);
-        half_t* vt = ar.halfs((size_t)M * C);
-        {   // V^T[b] = Wv · LN(x)_b^T  -> [C][L] per sample (swapped GEMM: the weight is the row operand)
+        const int Lp = (L + 7) & ~7;   // V^T rows are padded to 8 keys (16-byte row copies in the attention kernel)
+        half_t* vt = ar.halfs((size_t)n * C * Lp);
+        {   // V^T[b] = Wv · LN(x)_b^T  -> [C][Lp] per sample (swapped GEMM: the weight is the row operand)
             GemmParams p;
             p.A = P(s.v1_w); p.lda = C; p.sA = 0;
             p.W = nrm; p.ldw = C; p.sW = (long long)L * C;
-            p.M = C; p.N = L; p.K = C; p.batch = n;
-            p.C = vt; p.ldc = L; p.sC = (long long)C * L;
+            p.M = C; p.N = Lp; p.n_valid = L; p.K = C; p.batch = n;
+            p.C = vt; p.ldc = Lp; p.sC = (long long)C * Lp;
             ex.gemm(p);
         }
         half_t* ao = ar.halfs((size_t)M * C);
@@ -301,7 +302,7 @@ struct Run {
             AttnParams a;
             a.Q = qk; a.ldq = 2 * C; a.sQ = (long long)L * 2 * C;
             a.K = qk + C; a.ldk = 2 * C; a.sK = (long long)L * 2 * C;
-            a.Vt = vt; a.ldvt = L; a.sV = (long long)C * L;
+            a.Vt = vt; a.ldvt = Lp; a.sV = (long long)C * Lp;
             a.O = ao; a.ldo = C; a.sO = (long long)L * C;
             a.B = n; a.H = heads; a.Lq = L; a.Lk = L; a.d = d;
             a.scale = 1.0f / sqrtf((float)d);
@@ -334,23 +335,6 @@ struct Run {
         return {out, C, H, W};
     }
 };
-
-int check_attn_shapes(const ld_unet* u, int h, int w) {
-    // every attention level needs tokens % 8 == 0 (V^T rows are copied in 16-byte chunks)
-    int H = h, W = w;
-    int td = 0;
-    for (int lvl = 0; lvl < u->cfg.num_levels; ++lvl) {
-        bool any = false;
-        for (int r = 0; r < u->cfg.num_res_blocks[lvl]; ++r) any |= u->cfg.transformer_depth[td++] > 0;
-        if (lvl == u->cfg.num_levels - 1 && u->cfg.transformer_depth_middle > 0) any = true;
-        if (any && ((H * W) & 7)) return LD_ERR_SHAPE;
-        if (lvl != u->cfg.num_levels - 1) {
-            H = (H - 1) / 2 + 1;
-            W = (W - 1) / 2 + 1;
-        }
-    }
-    return LD_OK;
-}
 
 int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, hipStream_t stream,
                 size_t* dry_peak = nullptr) {
@@ -607,8 +591,7 @@ int ld_unet_forward(ld_unet* u, const float* x, const float* sigma, float* out, 
     if (u->ws_base == nullptr || !u->pt.all_loaded() || u->ctx_n == 0) return LD_ERR_STATE;
     if (n != u->ctx_n) return LD_ERR_SHAPE;
     if (n > u->max_n || h < 1 || w < 1) return LD_ERR_SHAPE;
-    int st = check_attn_shapes(u, h, w);
-    if (st != LD_OK) return st;
+    int st = LD_OK;
     if (n != u->plan_n || h != u->plan_h || w != u->plan_w) {   // new shape: plan it on the host before touching the GPU
         size_t peak = 0;
         st = run_forward(u, true, nullptr, nullptr, nullptr, n, h, w, eps_only, nullptr, &peak);

@@ -33,7 +33,8 @@ def test_tiny_unet_golden(tiny_unet, name):
 
 
 def test_tiny_unet_batch4_matches_batch2(tiny_unet):
-    """samples are independent: a batch of 4 = two batches of 2 (what the 8-GPU sharding relies on)."""
+    """samples are independent: a batch of 4 = two batches of 2 (what the 8-GPU sharding relies on).  Not bitwise:
+    tile / split-K choices follow the GEMM M dimension, so the fp32 summation order differs between batch sizes."""
     g = load_golden("unet_tiny_16x16")
     x = torch.cat([g["x"], g["x"].flip(0)]).to(DEV)
     s = torch.cat([g["sigma"], g["sigma"].flip(0)]).to(DEV)
@@ -42,7 +43,9 @@ def test_tiny_unet_batch4_matches_batch2(tiny_unet):
     d4 = tiny_unet.forward(x, s).cpu()
     tiny_unet.set_context(g["ctx"])
     d2 = tiny_unet.forward(g["x"].to(DEV), g["sigma"].to(DEV)).cpu()
-    assert torch.equal(d4[:2], d2) and torch.equal(d4[2:], d2.flip(0))
+    assert rel_l2(d4[:2], d2) < 3e-3 and rel_l2(d4[2:], d2.flip(0)) < 3e-3
+    d2b = tiny_unet.forward(g["x"].to(DEV), g["sigma"].to(DEV)).cpu()
+    assert torch.equal(d2, d2b), "same inputs, same shape: the step must be bitwise reproducible"
 
 
 def test_wrapper_hook_contract(tiny_unet):
