@@ -70,6 +70,10 @@ int ld_unet_set_context(ld_unet* u, const void* ctx, int dtype, int n, int token
 /* x, out: [n][in_channels][h][w] fp32 NCHW; sigma: [n] fp32 (sigma, not t).  out = denoised = x - eps * sigma.
  * eps_only != 0 writes the raw UNet output (fp32 of the fp16 eps) instead. */
 int ld_unet_forward(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, void* stream);
+/* one forward with a HIP-event pair around every launch (recorded on `stream`), summed per kernel class:
+ * 0 conv3x3 (implicit GEMM)  1 linear / 1x1 GEMM  2 attention  3 GroupNorm  4 LayerNorm  5 misc.  Synchronises the stream. */
+int ld_unet_profile(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, void* stream, double ms[6],
+                    double flops[6], int launches[6]);
 /* number of kernel launches of the last forward, and algorithmic FLOPs of it (2*M*N*K over every contraction) */
 int ld_unet_last_launches(const ld_unet* u);
 double ld_unet_last_flops(const ld_unet* u);

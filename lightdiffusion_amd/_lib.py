@@ -51,6 +51,7 @@ SIGNATURES = {
     "ld_unet_weight_bytes": (_Z, [_P]),
     "ld_unet_set_context": (_I, [_P, _P, _I, _I, _I, _P]),
     "ld_unet_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ld_unet_profile": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I)]),
     "ld_unet_last_launches": (_I, [_P]),
     "ld_unet_last_flops": (C.c_double, [_P]),
     "ld_vae_create": (_I, [C.POINTER(VAEConfig), C.POINTER(_P)]),

@@ -95,7 +95,43 @@ struct Arena {
     void release(size_t m) { off = m; }
 };
 
+// kernel classes for the per-class timing mode (ld_unet_profile): HIP events recorded on the launch stream
+enum KClass { KC_CONV3 = 0, KC_GEMM = 1, KC_ATTN = 2, KC_GNORM = 3, KC_LNORM = 4, KC_MISC = 5, KC_COUNT = 6 };
+
+struct Timing {
+    std::vector<hipEvent_t> ev;     // pool, pairs (start, stop)
+    std::vector<int> cls;
+    size_t used = 0;
+    double ms[KC_COUNT] = {0}, flops[KC_COUNT] = {0};
+    int launches[KC_COUNT] = {0};
+    hipEvent_t next() {
+        if (used == ev.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            ev.push_back(e);
+        }
+        return ev[used++];
+    }
+    void reset() {
+        used = 0;
+        cls.clear();
+        for (int i = 0; i < KC_COUNT; ++i) ms[i] = flops[i] = 0, launches[i] = 0;
+    }
+    void collect() {
+        for (size_t i = 0; i + 1 < used; i += 2) {
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+            ms[cls[i / 2]] += t;
+        }
+    }
+    void destroy() {
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+    }
+};
+
 struct Exec {
+    Timing* timing = nullptr;
     hipStream_t stream = nullptr;
     bool dry = false;
     Arena* arena = nullptr;
@@ -110,31 +146,53 @@ struct Exec {
     }
     bool overflow() const { return !dry && arena->peak > arena->cap; }
 
+    void t_begin(int c, double fl, int nl) {
+        if (timing == nullptr || dry) return;
+        timing->cls.push_back(c);
+        timing->flops[c] += fl;
+        timing->launches[c] += nl;
+        (void)hipEventRecord(timing->next(), stream);
+    }
+    void t_end() {
+        if (timing == nullptr || dry) return;
+        (void)hipEventRecord(timing->next(), stream);
+    }
+
     void gemm(GemmParams p) {
-        flops += 2.0 * p.M * (double)p.N * p.K * p.batch;
+        const double fl = 2.0 * p.M * (double)p.N * p.K * p.batch;
+        flops += fl;
         if (p.batch == 1) {
             p.partial = splitk_ws;
             p.partial_bytes = splitk_bytes;
         }
         launches += 1;
         if (dry || status != LD_OK) return;
+        t_begin(p.conv && p.ksize == 3 ? KC_CONV3 : KC_GEMM, fl, 1);
         note(gemm_launch(p, stream));
+        t_end();
     }
     void groupnorm(const half_t* x1, int C1, const half_t* x2, int C2, int n, int HW, const half_t* g, const half_t* b, float eps,
                    int silu, half_t* y) {
         const size_t m = arena->mark();
         float* ws = reinterpret_cast<float*>(arena->alloc(groupnorm_workspace_bytes(n, HW)));
         launches += 2;
+        t_begin(KC_GNORM, 0.0, 2);
         if (!dry && status == LD_OK) note(groupnorm_launch(x1, C1, x2, C2, n, HW, g, b, eps, silu, y, ws, stream));
+        t_end();
         arena->release(m);
     }
     void layernorm(const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int C) {
         launches += 1;
+        t_begin(KC_LNORM, 0.0, 1);
         if (!dry && status == LD_OK) note(layernorm_launch(x, g, b, y, rows, C, 1e-5f, stream));
+        t_end();
     }
     void attention(const AttnParams& p) {
-        flops += 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.d;
+        const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.d;
+        flops += fl;
         launches += 1;
+        t_begin(KC_ATTN, fl, 1);
         if (!dry && status == LD_OK) note(attention_launch(p, stream));
+        t_end();
     }
 };

@@ -59,6 +59,8 @@ struct ld_unet {
     int plan_n = 0, plan_h = 0, plan_w = 0;   // last shape validated against the reserved arena
     int last_launches = 0;
     double last_flops = 0.0;
+    Timing timing;
+    bool want_timing = false;
 };
 
 namespace {
@@ -348,6 +350,10 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
     ex.arena = dry ? &plan : &u->arena;
     ex.splitk_ws = u->splitk_ws;
     ex.splitk_bytes = u->splitk_bytes;
+    if (u->want_timing && !dry) {
+        u->timing.reset();
+        ex.timing = &u->timing;
+    }
     Arena& ar = *ex.arena;
     ar.release(0);
     const ld_unet_config& c = u->cfg;
@@ -356,7 +362,9 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
     // timestep embedding -> time_embed MLP -> all ResBlock emb_layers at once (every consumer applies SiLU first)
     half_t* temb = ar.halfs((size_t)n * mc);
     ex.launches += 1;
+    ex.t_begin(KC_MISC, 0.0, 1);
     if (!dry) ex.note(timestep_embed_launch(sigma, u->log_sigmas, 1000, n, mc, temb, nullptr, stream));
+    ex.t_end();
     half_t* e1 = ar.halfs((size_t)n * ted);
     R.linear(temb, mc, u->te0_w, u->te0_b, nullptr, e1, n, ted, mc, 1);
     half_t* semb = ar.halfs((size_t)n * ted);
@@ -407,7 +415,9 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
         a.N = n; a.Cin = c.in_channels; a.H = h; a.W = w; a.Cout = mc;
         ex.launches += 1;
         ex.flops += 2.0 * n * h * w * mc * 9.0 * c.in_channels;
+        ex.t_begin(KC_MISC, 2.0 * n * h * w * mc * 9.0 * c.in_channels, 1);
         if (!dry) ex.note(small_conv_in_launch(a, stream));
+        ex.t_end();
         f = {o, mc, h, w};
         hs.push_back(f);
     }
@@ -433,7 +443,9 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
         a.x_in = x; a.sigma = sigma; a.out = out;
         ex.launches += 1;
         ex.flops += 2.0 * n * f.H * f.W * f.C * 9.0 * c.out_channels;
+        ex.t_begin(KC_MISC, 2.0 * n * f.H * f.W * f.C * 9.0 * c.out_channels, 1);
         if (!dry) ex.note(small_conv_out_launch(a, stream));
+        ex.t_end();
     }
     u->last_launches = ex.launches;
     u->last_flops = ex.flops;
@@ -480,6 +492,7 @@ int ld_unet_create(const ld_unet_config* cfg, ld_unet** out) {
 void ld_unet_destroy(ld_unet* u) {
     if (u == nullptr) return;
     u->pt.destroy();
+    u->timing.destroy();
     if (u->ws_base) (void)hipFree(u->ws_base);
     if (u->log_sigmas) (void)hipFree(u->log_sigmas);
     delete u;
@@ -602,6 +615,23 @@ int ld_unet_forward(ld_unet* u, const float* x, const float* sigma, float* out, 
         u->plan_w = w;
     }
     return run_forward(u, false, x, sigma, out, n, h, w, eps_only, (hipStream_t)stream);
+}
+
+int ld_unet_profile(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, void* stream, double ms[6],
+                    double flops[6], int launches[6]) {
+    if (u == nullptr || ms == nullptr || flops == nullptr || launches == nullptr) return LD_ERR_ARG;
+    u->want_timing = true;
+    int st = ld_unet_forward(u, x, sigma, out, n, h, w, 0, stream);
+    u->want_timing = false;
+    if (st != LD_OK) return st;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return LD_ERR_HIP;
+    u->timing.collect();
+    for (int i = 0; i < KC_COUNT; ++i) {
+        ms[i] = u->timing.ms[i];
+        flops[i] = u->timing.flops[i];
+        launches[i] = u->timing.launches[i];
+    }
+    return LD_OK;
 }
 
 int ld_unet_last_launches(const ld_unet* u) { return u ? u->last_launches : 0; }

@@ -1,0 +1,66 @@
+"""Step-level runtime: the classifier-free-guided denoiser of one sampler step as a replayable hipGraph.
+
+One sampler step of the reference = `sampling_function` (LD.py:2609-2626): cat([x, x]) → UNet on N = 2B samples in
+the order [uncond, cond] → uncond + (cond - uncond) * cfg.  Here the 2B-sample input, sigma and output live in static
+device buffers, the ~300 kernel launches of the forward plus the guidance mix are captured once into a hipGraph and
+replayed per step (sigma is read from device memory, so one graph serves every step).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .unet import MI355XUNet
+
+
+class CFGDenoiser:
+    def __init__(self, unet: MI355XUNet, batch: int, h: int, w: int, cfg_scale: float, use_graph: bool = True):
+        self.unet, self.batch, self.cfg_scale = unet, batch, float(cfg_scale)
+        dev = unet.device
+        c = unet.cfg["in_channels"]
+        self.x2 = torch.zeros(2 * batch, c, h, w, dtype=torch.float32, device=dev)
+        self.sigma2 = torch.ones(2 * batch, dtype=torch.float32, device=dev)
+        self.den2 = torch.zeros_like(self.x2)
+        self.den = torch.zeros(batch, c, h, w, dtype=torch.float32, device=dev)
+        self.use_graph = use_graph
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+
+    def set_context(self, uncond: torch.Tensor, cond: torch.Tensor) -> None:
+        """uncond / cond: [1 or B, T, D].  Batched as the reference batches them: [uncond x B ; cond x B] (LD.py:2515-2547)."""
+        rep = lambda t: t if t.shape[0] == self.batch else t.expand(self.batch, -1, -1)
+        self.unet.set_context(torch.cat([rep(uncond), rep(cond)]).contiguous())
+        self._graph = None
+
+    def _body(self) -> None:
+        self.unet.forward(self.x2, self.sigma2, out=self.den2)
+        from ._lib import check, lib
+        check(lib().ld_op_cfg_combine(self.den2.data_ptr(), self.den.data_ptr(), self.cfg_scale, self.den.numel(),
+                                      torch.cuda.current_stream().cuda_stream), "ld_op_cfg_combine")
+
+    def _capture(self) -> None:
+        side = torch.cuda.Stream(device=self.unet.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._body()                      # warm-up outside capture (plans the shape, touches every kernel once)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(self.unet.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._body()
+        self._graph = g
+
+    def __call__(self, x: torch.Tensor, sigma: float) -> torch.Tensor:
+        """x [B,C,h,w] fp32 on the device, sigma a host scalar -> guided denoised x0 [B,C,h,w] (static buffer)."""
+        b = self.batch
+        self.x2[:b].copy_(x)
+        self.x2[b:].copy_(x)
+        self.sigma2.fill_(float(sigma))
+        if not self.use_graph:
+            self._body()
+        else:
+            if self._graph is None:
+                self._capture()
+            self._graph.replay()
+        return self.den

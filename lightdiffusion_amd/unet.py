@@ -126,6 +126,18 @@ class MI355XUNet:
                   "ld_unet_forward")
         return out
 
+    KERNEL_CLASSES = ("conv3x3", "gemm", "attention", "groupnorm", "layernorm", "misc")
+
+    def profile(self, x: torch.Tensor, sigma: torch.Tensor) -> dict:
+        """One forward with HIP events around every launch; returns {class: (ms, flops, launches)}."""
+        out = torch.empty_like(x)
+        ms, fl, nl = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int * 6)()
+        n, _, h, w = x.shape
+        with torch.cuda.device(self.device):
+            check(lib().ld_unet_profile(self._h, x.data_ptr(), sigma.data_ptr(), out.data_ptr(), n, h, w, _stream(), ms, fl, nl),
+                  "ld_unet_profile")
+        return {k: (ms[i], fl[i], nl[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
+
     # -- the reference's plugin seam
     def __call__(self, apply_model, params: dict) -> torch.Tensor:
         x = params["input"]
