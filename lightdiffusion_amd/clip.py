@@ -1,0 +1,200 @@
+"""CLIP-L text conditioning: prompt-weight parsing, 77-token chunking, the 12-layer causal text
+transformer and the per-token weight lerp.  Runs once per prompt, so — as the scope table says — it stays on
+PyTorch-ROCm ops (no HIP kernels here); its output is the payload of the one RCCL broadcast.
+
+Mirrors: token_weights / parse_parentheses (LD.py:4733-4780), SDTokenizer.tokenize_with_weights (LD.py:4936-5031),
+ClipTokenWeightEncoder.encode_token_weights (LD.py:4540-4569), SDClipModel.forward (LD.py:4692-4724),
+CLIPTextModel_ (LD.py:4413-4463), CLIP.tokenize / encode_from_tokens / clip_layer (LD.py:6222-6272).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+START_TOKEN, END_TOKEN = 49406, 49407
+_ESC_CLOSE, _ESC_OPEN = "\0\1", "\0\2"
+
+
+# ------------------------------------------------------------------ "(text:1.2)" emphasis syntax
+def _split_top_level_groups(text: str) -> List[str]:
+    """Cut `text` at top-level parenthesis groups: a cut before a '(' seen at depth 0 and after the ')' that returns the
+    depth to 0.  Depth may go negative on stray ')' (then nothing closes until it is back at 0) — same as the reference."""
+    pieces, start, depth = [], 0, 0
+    for i, ch in enumerate(text):
+        if ch == "(":
+            if depth == 0 and i > start:
+                pieces.append(text[start:i])
+                start = i
+            depth += 1
+        elif ch == ")":
+            depth -= 1
+            if depth == 0:
+                pieces.append(text[start:i + 1])
+                start = i + 1
+    if start < len(text):
+        pieces.append(text[start:])
+    return pieces
+
+
+def parse_prompt_weights(text: str, base: float = 1.0) -> List[Tuple[str, float]]:
+    """(segment, weight) list.  A "( ... )" group multiplies the weight by 1.1, or sets it to the number after the
+    group's last ':' when that parses as a float; groups nest."""
+    out: List[Tuple[str, float]] = []
+    for piece in _split_top_level_groups(text):
+        if len(piece) >= 2 and piece[0] == "(" and piece[-1] == ")":
+            inner, w = piece[1:-1], base * 1.1
+            colon = inner.rfind(":")
+            if colon > 0:
+                try:
+                    w, inner = float(inner[colon + 1:]), inner[:colon]
+                except ValueError:
+                    pass
+            out.extend(parse_prompt_weights(inner, w))
+        else:
+            out.append((piece, base))
+    return out
+
+
+def escape_important(text: str) -> str:
+    return text.replace("\\)", _ESC_CLOSE).replace("\\(", _ESC_OPEN)
+
+
+def unescape_important(text: str) -> str:
+    return text.replace(_ESC_CLOSE, ")").replace(_ESC_OPEN, "(")
+
+
+class PromptTokenizer:
+    """Word-level BPE front end + the reference's chunking rules: [BOS] tokens... [EOS] padded with EOS to 77; words of
+    fewer than 8 tokens are never split across chunks; longer words are split and the chunk is closed with EOS."""
+
+    max_word_length = 8
+
+    def __init__(self, word_tokenizer: Callable[[str], List[int]], max_length: int = 77, start_token: int = START_TOKEN,
+                 end_token: int = END_TOKEN, pad_with_end: bool = True):
+        self.word_tokenizer = word_tokenizer
+        self.max_length, self.start_token, self.end_token = max_length, start_token, end_token
+        self.pad_token = end_token if pad_with_end else 0
+
+    @classmethod
+    def from_pretrained(cls, tokenizer_dir: str) -> "PromptTokenizer":
+        """Build on HuggingFace's CLIPTokenizer files (the reference loads them from `_internal/sd1_tokenizer/`)."""
+        from transformers import CLIPTokenizer
+        tok = CLIPTokenizer.from_pretrained(tokenizer_dir)
+        empty = tok("")["input_ids"]
+        return cls(lambda w: tok(w)["input_ids"][1:-1], start_token=empty[0], end_token=empty[1])
+
+    def tokenize_with_weights(self, text: str) -> List[List[Tuple[int, float]]]:
+        words: List[List[Tuple[int, float]]] = []
+        for seg, w in parse_prompt_weights(escape_important(text), 1.0):
+            for word in unescape_important(seg).replace("\n", " ").split(" "):
+                if word:
+                    words.append([(t, w) for t in self.word_tokenizer(word)])
+        chunks: List[List[Tuple[int, float]]] = [[(self.start_token, 1.0)]]
+        cur = chunks[0]
+        room = self.max_length - 1                       # slots before the closing EOS
+        for group in words:
+            big = len(group) >= self.max_word_length
+            while group:
+                if len(group) + len(cur) > room:
+                    left = room - len(cur)
+                    if big:
+                        cur.extend(group[:left])
+                        cur.append((self.end_token, 1.0))
+                        group = group[left:]
+                    else:
+                        cur.append((self.end_token, 1.0))
+                        cur.extend([(self.pad_token, 1.0)] * left)
+                    cur = [(self.start_token, 1.0)]
+                    chunks.append(cur)
+                else:
+                    cur.extend(group)
+                    group = []
+        cur.append((self.end_token, 1.0))
+        cur.extend([(self.pad_token, 1.0)] * (self.max_length - len(cur)))
+        return chunks
+
+
+# ------------------------------------------------------------------ text transformer
+class CLIPTextModel:
+    """Functional CLIP-L on a torch device, fp32 compute (the reference keeps fp16 weights but casts them to the fp32
+    activations per call — `manual_cast`, LD.py:2418-2429 — so the arithmetic is fp32)."""
+
+    def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], device="cuda:0", weight_dtype=torch.float32):
+        self.cfg, self.device = dict(cfg), torch.device(device)
+        self.w = {k: v.to(weight_dtype).to(self.device) for k, v in weights.items()}
+
+    def _lin(self, x, p):
+        return F.linear(x, self.w[p + ".weight"].float(), self.w[p + ".bias"].float())
+
+    def _ln(self, x, p):
+        return F.layer_norm(x, (x.shape[-1],), self.w[p + ".weight"].float(), self.w[p + ".bias"].float(), 1e-5)
+
+    @torch.no_grad()
+    def __call__(self, tokens: torch.Tensor, intermediate_output: Optional[int] = None):
+        """-> (last hidden state after final LN, final-LN'd hidden state after layer `intermediate_output` or None, pooled)."""
+        P = "text_model."
+        h, heads, nl = self.cfg["hidden_size"], self.cfg["num_attention_heads"], self.cfg["num_hidden_layers"]
+        tokens = tokens.to(self.device)
+        x = self.w[P + "embeddings.token_embedding.weight"].float()[tokens] + self.w[P + "embeddings.position_embedding.weight"].float()
+        L = x.shape[1]
+        mask = torch.full((L, L), float("-inf"), device=self.device).triu_(1)
+        stop = None if intermediate_output is None else (nl + intermediate_output if intermediate_output < 0 else intermediate_output)
+        inter = None
+        for i in range(nl):
+            p = f"{P}encoder.layers.{i}"
+            n = self._ln(x, p + ".layer_norm1")
+            q, k, v = (self._lin(n, f"{p}.self_attn.{t}_proj").view(-1, L, heads, h // heads).transpose(1, 2) for t in "qkv")
+            a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(h // heads) + mask, dim=-1) @ v
+            x = x + self._lin(a.transpose(1, 2).reshape(-1, L, h), p + ".self_attn.out_proj")
+            m = self._lin(self._ln(x, p + ".layer_norm2"), p + ".mlp.fc1")
+            x = x + self._lin(m * torch.sigmoid(1.702 * m), p + ".mlp.fc2")
+            if i == stop:
+                inter = x.clone()
+        x = self._ln(x, P + "final_layer_norm")
+        if inter is not None:
+            inter = self._ln(inter, P + "final_layer_norm")
+        pooled = x[torch.arange(x.shape[0], device=self.device), tokens.to(torch.int).argmax(dim=-1)]
+        return x, inter, pooled
+
+
+class CLIP:
+    """The object `CLIPTextEncode.encode(clip, text)` drives (LD.py:6222-6272)."""
+
+    def __init__(self, text_model: CLIPTextModel, tokenizer: Optional[PromptTokenizer] = None, layer_idx: Optional[int] = None):
+        self.text_model, self.tokenizer, self.layer_idx = text_model, tokenizer, layer_idx
+
+    def clone(self) -> "CLIP":
+        return CLIP(self.text_model, self.tokenizer, self.layer_idx)
+
+    def clip_layer(self, layer_idx: int) -> None:           # CLIPSetLastLayer → clip skip
+        self.layer_idx = layer_idx
+
+    def tokenize(self, text: str):
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer attached: build one with PromptTokenizer.from_pretrained(<sd1_tokenizer dir>)")
+        return {"l": self.tokenizer.tokenize_with_weights(text)}
+
+    def _encode_ids(self, ids: List[List[int]]):
+        last, inter, pooled = self.text_model(torch.tensor(ids, dtype=torch.long), intermediate_output=self.layer_idx)
+        return (last if inter is None else inter).float(), pooled.float()
+
+    def encode_from_tokens(self, tokens, return_pooled: bool = False):
+        pairs: Sequence[Sequence[Tuple[int, float]]] = tokens["l"] if isinstance(tokens, dict) else tokens
+        ids = [[t for t, _ in sec] for sec in pairs]
+        weighted = any(w != 1.0 for sec in pairs for _, w in sec)
+        n = len(ids)
+        if weighted or n == 0:
+            ids = ids + [[START_TOKEN, END_TOKEN] + [END_TOKEN] * (max(len(s) for s in ids) - 2 if ids else 75)]
+        out, pooled = self._encode_ids(ids)
+        secs = []
+        for k in range(n):
+            z = out[k:k + 1]
+            if weighted:
+                w = torch.tensor([w for _, w in pairs[k]], dtype=z.dtype, device=z.device)[None, :, None]
+                z = torch.where(w != 1.0, (z - out[-1:]) * w + out[-1:], z)
+            secs.append(z)
+        cond = torch.cat(secs, dim=-2).cpu()                 # intermediate_device() is the CPU in the reference
+        return (cond, pooled[0:1].cpu()) if return_pooled else cond

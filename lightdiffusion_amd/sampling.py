@@ -229,7 +229,13 @@ def sampling_function(model, x, timestep, uncond, cond, cond_scale, model_option
             t = t.expand(b, -1, -1)
         return t
 
-    ctx = _cat_ctx([ctx_of(uncond), ctx_of(cond)])
+    # the batched context is step-invariant: build it once per run (cache lives in the guider's model_options)
+    cache = model_options.setdefault("_ld_ctx_cache", {})
+    key = (b, id(uncond), id(cond))
+    if key not in cache:
+        cache.clear()
+        cache[key] = _cat_ctx([ctx_of(uncond), ctx_of(cond)]).contiguous()
+    ctx = cache[key]
     x2 = torch.cat([x, x])
     s2 = torch.cat([timestep, timestep])
     c = {"c_crossattn": ctx, "transformer_options": {"cond_or_uncond": [1, 0], "sigmas": timestep}}
@@ -304,6 +310,8 @@ class CFGGuider:
         noise, latent_image = noise.to(device), latent_image.to(device)
         if torch.count_nonzero(latent_image) > 0:                 # don't shift the empty latent (LD.py:2938-2941)
             latent_image = self.inner_model.process_latent_in(latent_image)
+        self.model_options = dict(self.model_options)
+        self.model_options.pop("_ld_ctx_cache", None)
         extra_args = {"model_options": self.model_options, "seed": seed}
         samples = sampler.sample(self, sigmas, extra_args, callback, noise, latent_image, denoise_mask, disable_pbar)
         out = self.inner_model.process_latent_out(samples.to(torch.float32))

@@ -61,7 +61,7 @@ _DEFS = {
     # CLIP-L (LD.py:4268-4487)
     "CLIPAttention", "CLIPMLP", "CLIPLayer", "CLIPEncoder", "CLIPEmbeddings", "CLIPTextModel_", "CLIPTextModel",
     # prompt weighting parser (LD.py:4733-4793)
-    "parse_parentheses", "token_weights", "escape_important", "unescape_important",
+    "parse_parentheses", "token_weights", "escape_important", "unescape_important", "SDTokenizer",
     # UNet (LD.py:5083-5767)
     "forward_timestep_embed1", "Upsample1", "Downsample1", "ResBlock1", "apply_control1", "UNetModel1",
     # model wrappers (LD.py:5779-5976)
@@ -109,6 +109,7 @@ def load_reference(path: str = REF_PATH) -> types.SimpleNamespace:
         "taesd_preview": lambda x: None,
         "copy": __import__("copy"), "uuid": __import__("uuid"),
         "isfunction": __import__("inspect").isfunction,
+        "CLIPTokenizer": None,      # default argument of SDTokenizer.__init__; goldens inject their own word tokenizer
         "optimized_attention_for_device": lambda device, mask=False, small_input=False: ns["attention_pytorch"],
     }
     done = set()

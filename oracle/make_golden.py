@@ -236,6 +236,36 @@ def g_clip():
     print("wrote prompt_weights.json")
 
 
+# ------------------------------------------------------------------ 6b. 77-token chunking with an injected word tokenizer
+class FakeWordTokenizer:
+    """Deterministic stand-in for HF CLIPTokenizer (its vocab files do not travel): word -> 1 + len(word)//4 ids."""
+
+    @classmethod
+    def from_pretrained(cls, path):
+        return cls()
+
+    @staticmethod
+    def ids(word):
+        import zlib
+        return [100 + zlib.crc32(f"{word}#{i}".encode()) % 40000 for i in range(1 + len(word) // 4)]
+
+    def __call__(self, word):
+        return {"input_ids": [49406] + (self.ids(word) if word else []) + [49407]}
+
+    def get_vocab(self):
+        return {}
+
+
+def g_tokens():
+    tok = ref.SDTokenizer(tokenizer_path="unused", tokenizer_class=FakeWordTokenizer)
+    long_prompt = " ".join(f"word{i}" for i in range(60)) + " " + "x" * 40 + " tail (heavy:1.5) end"
+    prompts = ["a photo of a cat", "a (red:1.4) car, ((masterpiece))", long_prompt, "", "multi\nline \\(kept\\) (a (b:0.5) c:2)"]
+    out = {p: tok.tokenize_with_weights(p) for p in prompts}
+    with open(os.path.join(OUT, "token_chunks.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote token_chunks.json", {k[:20]: len(v) for k, v in out.items()})
+
+
 # ------------------------------------------------------------------ 7. bislerp
 def g_bislerp():
     x = rnd((2, 4, 8, 6), 71)
@@ -245,6 +275,6 @@ def g_bislerp():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "blocks", "unets", "samplers", "vae", "clip", "bislerp"]
+    which = sys.argv[1:] or ["schedules", "blocks", "unets", "samplers", "vae", "clip", "tokens", "bislerp"]
     for n in which:
         globals()["g_" + n]()

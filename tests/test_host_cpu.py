@@ -1,0 +1,134 @@
+"""CPU: host-side logic of the product package (no HIP compute) against the reference-generated goldens, and the
+N>1 path (broadcast / shard / gather) over gloo with world_size 2."""
+import json
+import os
+import zlib
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT, load_golden, rel_l2
+from lightdiffusion_amd import weights as W
+
+
+def test_schedules_match_reference():
+    from lightdiffusion_amd import sampling as S
+    g = load_golden("schedules")
+    ms = S.ModelSampling()
+    assert torch.equal(ms.sigmas, g["sigmas"]) and torch.equal(ms.log_sigmas, g["log_sigmas"])
+    assert torch.equal(S.calculate_sigmas(ms, "karras", 20), g["karras20"])
+    assert torch.equal(S.calculate_sigmas(ms, "normal", 30), g["normal30"])
+    ks = S.KSampler1.__new__(S.KSampler1)
+    ks.model = type("M", (), {"get_model_object": staticmethod(lambda name: ms)})()
+    ks.scheduler = "normal"
+    ks.set_steps(10, 0.45)                                   # hires-fix: 22 normal sigmas, last 11 kept (LD.py:3097-3104)
+    assert torch.equal(ks.sigmas, g["normal10_d045"])
+    assert torch.equal(ms.timestep(g["probe_sigma"]), g["probe_t"]) and torch.equal(ms.sigma(g["tq"]), g["sigma_of_t"])
+    for (a, b), (d, u) in zip(((14.6, 11.7), (1.0, 0.5), (0.05, 0.0)), g["anc"].tolist()):
+        assert S.get_ancestral_step(a, b) == (d, u)
+    with pytest.raises(ValueError):
+        S.calculate_sigmas(ms, "exponential", 10)
+    assert torch.equal(S.prepare_noise(torch.zeros(1, 4, 8, 8), 7), torch.randn(1, 4, 8, 8, generator=torch.manual_seed(7)))
+
+
+def test_prompt_weights_and_chunking():
+    from lightdiffusion_amd.clip import PromptTokenizer, escape_important, parse_prompt_weights
+    g = json.load(open(os.path.join(GOLDEN, "prompt_weights.json")))
+    for text, want in g.items():
+        assert [list(t) for t in parse_prompt_weights(escape_important(text), 1.0)] == want
+    word_ids = lambda w: [100 + zlib.crc32(f"{w}#{i}".encode()) % 40000 for i in range(1 + len(w) // 4)]
+    tok = PromptTokenizer(word_ids)
+    chunks = json.load(open(os.path.join(GOLDEN, "token_chunks.json")))
+    for text, want in chunks.items():
+        got = tok.tokenize_with_weights(text)
+        assert [[list(p) for p in c] for c in got] == want, text
+        assert all(len(c) == 77 and c[0][0] == 49406 for c in got)
+
+
+def test_clip_text_model_and_weight_lerp():
+    from lightdiffusion_amd.clip import CLIP, CLIPTextModel
+    g = load_golden("clip_tiny")
+    cfg = W.tiny_clip_config()
+    tm = CLIPTextModel(cfg, W.synth_state_dict(W.clip_param_shapes(cfg)), device="cpu")
+    last, inter, pooled = tm(g["tokens"], intermediate_output=-2)
+    assert rel_l2(last, g["last"]) < 5e-6 and rel_l2(inter, g["inter_m2"]) < 5e-6 and rel_l2(pooled, g["pooled"]) < 5e-6
+    clip = CLIP(tm, None, layer_idx=-2)
+    toks = g["tokens"][0].tolist()
+    plain = clip.encode_from_tokens([[(t, 1.0) for t in toks]])
+    assert rel_l2(plain, g["inter_m2"][:1]) < 5e-6
+    cond, pooled1 = clip.encode_from_tokens([[(t, 1.3 if 2 <= i < 5 else 1.0) for i, t in enumerate(toks)]], return_pooled=True)
+    empty = clip.encode_from_tokens([[(49406, 1.0)] + [(49407, 1.0)] * 76])
+    assert torch.allclose(cond[0, 5:], plain[0, 5:], atol=1e-6)
+    assert torch.allclose(cond[0, 2:5], (plain[0, 2:5] - empty[0, 2:5]) * 1.3 + empty[0, 2:5], atol=1e-5)
+    assert cond.shape == (1, 77, cfg["hidden_size"]) and pooled1.shape == (1, cfg["hidden_size"])
+    with pytest.raises(RuntimeError):
+        clip.tokenize("needs a tokenizer")
+
+
+def test_bislerp_matches_reference():
+    from lightdiffusion_amd.nodes import LatentUpscale, bislerp
+    g = load_golden("bislerp")
+    assert rel_l2(bislerp(g["x"], 12, 16), g["y2x"]) < 2e-6 and rel_l2(bislerp(g["x"], 9, 11), g["y_odd"]) < 2e-6
+    up = LatentUpscale().upscale({"samples": torch.randn(1, 4, 8, 8)}, "bislerp", 128, 128)[0]["samples"]
+    assert up.shape == (1, 4, 16, 16)
+
+
+def test_node_surface_shapes_and_errors():
+    from lightdiffusion_amd import nodes, sampling
+    lat = nodes.EmptyLatentImage().generate(512, 768, 3)[0]["samples"]
+    assert lat.shape == (3, 4, 96, 64) and float(lat.abs().sum()) == 0.0
+    with pytest.raises(ValueError):
+        sampling.ksampler("ddim")
+    with pytest.raises(NotImplementedError):
+        sampling.ksampler("dpm_adaptive")
+    ctx = sampling._cat_ctx([torch.zeros(1, 77, 8), torch.ones(1, 154, 8)])      # lcm padding by repetition (LD.py:647-663)
+    assert ctx.shape == (2, 154, 8)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import lightdiffusion_amd._lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        L.lib()
+
+
+# ------------------------------------------------------------------ world_size 2 over gloo
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from lightdiffusion_amd import dist as D
+    r, w, _ = D.init("gloo")
+    assert (r, w) == (rank, world)
+    shapes = [(1, 77, 16), (1, 154, 16)]
+    src = [torch.arange(77 * 16, dtype=torch.float32).view(shapes[0]), torch.full(shapes[1], 3.5)] if rank == 0 else [None, None]
+    cond, uncond = D.broadcast_conditioning(src, shapes, src=0, device=torch.device("cpu"))
+    ok = bool(cond[0, 1, 0] == 16.0) and bool((uncond == 3.5).all())
+    rows = D.shard_rows(5, rank, world)
+    noise = D.full_batch_noise((5, 4, 8, 8), 42, rows)
+    full = torch.randn(5, 4, 8, 8, generator=torch.manual_seed(42))
+    ok = ok and torch.equal(noise, full[rows])
+    imgs = torch.full((rows.stop - rows.start, 2, 2, 3), float(rank))
+    allimg = D.gather_images(imgs, dst=0)
+    if rank == 0:
+        ok = ok and allimg.shape[0] == 5 and allimg[:3].eq(0).all().item() and allimg[3:].eq(1).all().item()
+    else:
+        ok = ok and allimg is None
+    q.put((rank, ok, (rows.start, rows.stop)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 500
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert [r[1] for r in res] == [True, True]
+    assert [r[2] for r in res] == [(0, 3), (3, 5)]

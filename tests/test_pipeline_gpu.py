@@ -1,0 +1,102 @@
+"""GPU parity of the sampling call surface: the reference's own sampler trajectories (goldens produced by its
+common_ksampler / sample / KSAMPLER stack on the tiny UNet, fp32 CPU) against this package's mirror driving the HIP UNet.
+Tolerance: a trajectory is 4-6 CFG steps (cfg 7-8 amplifies the cond/uncond difference) of an fp16-storage UNet whose
+single-call bound is rel-L2 5e-3 — the end latent must agree to rel-L2 3e-2."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from lightdiffusion_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TRAJ_TOL = 3e-2
+
+
+@pytest.fixture(scope="module")
+def stack():
+    from lightdiffusion_amd import nodes
+    model, clip, vae = nodes.load_synthetic(DEV, max_batch=2, max_hw=(16, 16), tiny=True)
+    return model, clip, vae
+
+
+def conds(g):
+    return [[g["pos"], {"pooled_output": None}]], [[g["neg"], {"pooled_output": None}]]
+
+
+def test_euler_ancestral_txt2img_and_img2img(stack):
+    from lightdiffusion_amd import nodes
+    model = stack[0]
+    g = load_golden("samplers")
+    pos, neg = conds(g)
+    lat = nodes.EmptyLatentImage().generate(128, 96, 1)[0]
+    out = nodes.KSampler2().sample(model, 1234, 6, 7.5, "euler_ancestral", "normal", pos, neg, lat)[0]["samples"]
+    assert out.device.type == "cpu" and out.shape == g["euler_a_txt2img"].shape
+    assert rel_l2(out, g["euler_a_txt2img"]) < TRAJ_TOL
+    out = nodes.KSampler2().sample(model, 77, 4, 8.0, "euler_ancestral", "normal", pos, neg, {"samples": g["lat2"]}, denoise=0.45)[0]["samples"]
+    assert rel_l2(out, g["euler_a_img2img"]) < TRAJ_TOL
+
+
+def test_dpmpp_2m_and_sde_with_injected_noise(stack):
+    from lightdiffusion_amd import sampling as S
+    model = stack[0]
+    g = load_golden("samplers")
+    pos, neg = conds(g)
+    lat = torch.zeros(1, 4, 12, 16)
+    sig = S.calculate_sigmas(model.get_model_object("model_sampling"), "karras", 6)
+    noise = S.prepare_noise(lat, 99)
+    out = S.sample(model, noise, pos, neg, 7.0, model.load_device, S.ksampler("dpmpp_2m_sde", {"eta": 0.0}), sig, model.model_options,
+                   latent_image=lat, seed=99).cpu()
+    assert rel_l2(out, g["dpmpp2m_eta0"]) < TRAJ_TOL
+    gen = torch.Generator().manual_seed(5)
+    ns = lambda s, sn: torch.randn(lat.shape, generator=gen).to(DEV)
+    out = S.sample(model, noise, pos, neg, 7.0, model.load_device, S.ksampler("dpmpp_2m_sde", {"eta": 1.0, "noise_sampler": ns}), sig,
+                   model.model_options, latent_image=lat, seed=99).cpu()
+    assert rel_l2(out, g["dpmpp2m_sde_injected"]) < TRAJ_TOL
+    # default eta=1 noise (torchsde stand-in): runs, finite, seed-reproducible
+    a = S.sample(model, noise, pos, neg, 7.0, model.load_device, S.ksampler("dpmpp_2m_sde"), sig, model.model_options, latent_image=lat, seed=3)
+    b = S.sample(model, noise, pos, neg, 7.0, model.load_device, S.ksampler("dpmpp_2m_sde"), sig, model.model_options, latent_image=lat, seed=3)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_toy_trajectories_on_device():
+    """k-diffusion update arithmetic alone (toy denoiser), against the reference's functions."""
+    from lightdiffusion_amd import sampling as S
+    g = load_golden("samplers")
+    toy = lambda x, s, **kw: x * (1.0 / (1.0 + s.view(-1, 1, 1, 1) ** 2))
+    sig = S.get_sigmas_karras(8, 0.03, 14.6)
+    x0 = g["toy_x0"].to(DEV)
+    torch.manual_seed(7)
+    assert rel_l2(S.sample_euler_ancestral(toy, x0, sig).cpu(), g["toy_euler_a"]) < 1e-5
+    assert rel_l2(S.sample_dpmpp_2m_sde(toy, x0, sig, eta=0.0).cpu(), g["toy_dpmpp2m"]) < 1e-5
+    assert rel_l2(S.sample_dpmpp_2m_sde(toy, x0, sig, eta=0.0, solver_type="heun").cpu(), g["toy_dpmpp2m_heun"]) < 1e-5
+
+
+def test_graph_replay_equals_eager(stack):
+    from lightdiffusion_amd.pipeline import CFGDenoiser
+    unet = stack[0].model.diffusion_model
+    g = load_golden("samplers")
+    x = torch.randn(1, 4, 12, 16, generator=torch.Generator().manual_seed(1)).to(DEV) * 3
+    outs = []
+    for use_graph in (False, True):
+        d = CFGDenoiser(unet, 1, 12, 16, 7.5, use_graph=use_graph)
+        d.set_context(g["neg"], g["pos"])
+        r = [d(x, 2.0).clone(), d(x, 0.5).clone(), d(x, 2.0).clone()]
+        outs.append(r)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[1][0], outs[1][2]) and not torch.equal(outs[1][0], outs[1][1])
+
+
+def test_txt2img_end_to_end_tiny(stack):
+    from lightdiffusion_amd import nodes
+    model, clip, vae = stack
+    toks = [[(49406, 1.0)] + [(1000 + i, 1.2 if i < 3 else 1.0) for i in range(10)] + [(49407, 1.0)] * 66]
+    neg = [[(49406, 1.0)] + [(49407, 1.0)] * 76]
+    img = nodes.txt2img(model, clip.clone(), vae, toks, neg, width=128, height=128, batch_size=2, seed=5, steps=4, cfg=6.0,
+                        sampler_name="euler_ancestral", scheduler="normal")
+    assert img.shape == (2, 128, 128, 3) and img.dtype == torch.float32 and img.device.type == "cpu"
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0 and torch.isfinite(img).all()
+    img2 = nodes.txt2img(model, clip.clone(), vae, toks, neg, width=128, height=128, batch_size=2, seed=5, steps=4, cfg=6.0,
+                         sampler_name="euler_ancestral", scheduler="normal")
+    assert torch.equal(img, img2)
