@@ -22,6 +22,7 @@ constexpr int KT_KEYS = 64;   // keys per LDS tile
 template <int DK>
 __global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams p) {
     constexpr int DV = (DK + 1) / 2;            // 32-row tiles of O^T
+    constexpr bool ONES = (DK & 1) != 0;        // d <= 16*DK < 32*DV: a spare V^T row exists -> row-sum of P by MFMA
     constexpr int KLD = 16 * DK + 8;            // K tile row stride (halfs)
     constexpr int VLD = KT_KEYS + 8;            // V^T tile row stride (halfs)
     constexpr int KCH = KT_KEYS * 2 * DK;       // 16-byte chunks in a (padded-d) K tile
@@ -72,8 +73,11 @@ __global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams
         for (int i = 0; i < VIT; ++i) {
             const int q = tid + i * AT_THREADS;
             const int row = q >> 3, cc = q & 7;
-            const bool ok = q < VCH && row < d && key0 + cc * 8 < p.Lk;   // Lk % 8 == 0 not required: see tail fix below
-            rv[i] = ok ? ld16(Vg + (long long)row * p.ldvt + key0 + cc * 8) : zero16();
+            const bool ok = q < VCH && row < d && key0 + cc * 8 < p.Lk;
+            // spare row 32*DV-1 := 1.0 (fp16 0x3C00): O^T row 32*DV-1 then accumulates sum_k P[k], the softmax
+            // denominator, on the matrix core instead of 16 VALU adds per tile
+            const uint4 fill = (ONES && row == 32 * DV - 1) ? make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u) : zero16();
+            rv[i] = ok ? ld16(Vg + (long long)row * p.ldvt + key0 + cc * 8) : fill;
         }
     };
     auto commit = [&]() {
@@ -139,12 +143,12 @@ __global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams
             half8 pf[2];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float pe = exp2f(s[e] * c2 - mc);
-                psum += pe;
+                const float pe = __builtin_amdgcn_exp2f(s[e] * c2 - mc);   // raw v_exp_f32: argument <= 0, flush of denormals is fine
+                if (!ONES) psum += pe;
                 pf[e >> 3][e & 7] = (half_t)pe;
             }
             if (__any(m_new > m_run)) {
-                const float alpha = exp2f((m_run - m_new) * c2);
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
                 l_run *= alpha;
 #pragma unroll
                 for (int tt = 0; tt < DV; ++tt)
@@ -163,7 +167,13 @@ __global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams
         }
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if (ONES) {
+        // row 32*DV-1 = tile DV-1, local row 31 = register 15 of the upper half-wave (row = (r&3) + 8*(r>>2) + 4*h)
+        l_tot = __shfl(o[DV - 1][15], 32 + r, 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.0f / l_tot;
     if (qrow < p.Lq) {
         half_t* Og = p.O + (long long)b * p.sO + (long long)qrow * p.ldo + head * d;

@@ -360,7 +360,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     int sk = p.splitk;
     if (sk == 0) {   // auto: fill ~2 blocks per CU when the tile grid alone cannot
         sk = 1;
-        if (p.batch == 1 && p.partial != nullptr && tiles < 192 && KT >= 8) {
+        if (p.batch == 1 && p.partial != nullptr && tiles < 384 && KT >= 8) {
             sk = (512 + tiles - 1) / tiles;
             if (sk > KT / 4) sk = KT / 4;
             if (sk > 32) sk = 32;

@@ -5,9 +5,12 @@
 #include "gemm.h"
 
 // ---- norm.hip
-static inline int gn_num_chunks(int HW) {
-    int p = (HW + 63) / 64;
-    return p < 1 ? 1 : (p > 256 ? 256 : p);
+// pixel chunks per image: aim at ~2048 blocks (x 4 channel slabs x n images), at least 8 pixels per chunk, at most 256 chunks
+static inline int gn_num_chunks(int n_img, int HW) {
+    int p = 2048 / (4 * (n_img < 1 ? 1 : n_img));
+    if (p > HW / 8) p = HW / 8;
+    if (p > 256) p = 256;
+    return p < 1 ? 1 : p;
 }
 size_t groupnorm_workspace_bytes(int n_img, int HW);
 int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, const half_t* gamma,

@@ -8,16 +8,30 @@ namespace {
 // 3x3 pad-1 conv, Cin <= 4, fp32 NCHW input (the sampler's latent) -> NHWC fp16.  Each thread: one pixel x 8 output
 // channels; the [Cout][9*Cin] filter bank sits in LDS.  Fuses EPS.calculate_input (x / sqrt(sigma^2+1), rounded to
 // fp16 like the reference's `.to(dtype)`, LD.py:5842) or the VAE's 1x1 post_quant_conv (LD.py:3470-3471).
+template <int CIN>
 __global__ __launch_bounds__(256) void small_conv_in_kernel(const SmallConvInArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    half_t* wl = reinterpret_cast<half_t*>(smem_raw);           // [Cout][9*Cin]
-    const int KK = 9 * a.Cin;
-    for (int i = threadIdx.x; i < a.Cout * KK; i += blockDim.x) wl[i] = a.w[i];
+    half_t* wl = reinterpret_cast<half_t*>(smem_raw);           // transposed filter bank [9*CIN][Cout]: 8 couts = one 16-byte read
+    constexpr int KK = 9 * CIN;
+    for (int i = threadIdx.x; i < a.Cout * KK; i += blockDim.x) {
+        const int o = i / KK, k = i - o * KK;
+        wl[k * a.Cout + o] = a.w[i];
+    }
+    float pw[CIN][CIN], pb[CIN];
+    if (a.pre_w != nullptr) {
+#pragma unroll
+        for (int o = 0; o < CIN; ++o) {
+            pb[o] = (float)a.pre_b[o];
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) pw[o][c] = (float)a.pre_w[o * CIN + c];
+        }
+    }
     __syncthreads();
     const int cgroups = a.Cout >> 3;
     const long long total = (long long)a.N * a.H * a.W * cgroups;
+    const long long plane = (long long)a.H * a.W;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
-        const int cg = (int)(q % cgroups);
+        const int cg = (int)(q % cgroups);          // channel group fastest: the lanes of a wave share the pixel -> broadcast loads
         long long pix = q / cgroups;
         const int x = (int)(pix % a.W);
         pix /= a.W;
@@ -28,34 +42,37 @@ __global__ __launch_bounds__(256) void small_conv_in_kernel(const SmallConvInArg
             inscale = 1.0f / sqrtf(s * s + 1.0f);
         }
         float acc[8];
-        {
-            float bb[8];
-            unpack8(ld16(a.b + cg * 8), bb);
+        unpack8(ld16(a.b + cg * 8), acc);
+        const float* xn = a.x + (long long)n * CIN * plane;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = bb[j];
-        }
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = y + ky - 1;
             if ((unsigned)iy >= (unsigned)a.H) continue;
+#pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = x + kx - 1;
                 if ((unsigned)ix >= (unsigned)a.W) continue;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int c = 0; c < a.Cin; ++c)
-                    v[c] = (float)(half_t)(a.x[(((long long)n * a.Cin + c) * a.H + iy) * a.W + ix] * inscale);
+                float v[CIN];
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) v[c] = (float)(half_t)(xn[c * plane + (long long)iy * a.W + ix] * inscale);
                 if (a.pre_w != nullptr) {
-                    float t[4];
-                    for (int o = 0; o < a.Cin; ++o) {
-                        float s = (float)a.pre_b[o];
-                        for (int c = 0; c < a.Cin; ++c) s += (float)a.pre_w[o * a.Cin + c] * v[c];
+                    float t[CIN];
+#pragma unroll
+                    for (int o = 0; o < CIN; ++o) {
+                        float s = pb[o];
+#pragma unroll
+                        for (int c = 0; c < CIN; ++c) s += pw[o][c] * v[c];
                         t[o] = (float)(half_t)s;
                     }
-                    for (int c = 0; c < a.Cin; ++c) v[c] = t[c];
-                }
-                const int tap = (ky * 3 + kx) * a.Cin;
-                for (int c = 0; c < a.Cin; ++c) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += v[c] * (float)wl[(cg * 8 + j) * KK + tap + c];
+                    for (int c = 0; c < CIN; ++c) v[c] = t[c];
+                }
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) {
+                    float w8[8];
+                    unpack8(ld16(wl + ((ky * 3 + kx) * CIN + c) * a.Cout + cg * 8), w8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += v[c] * w8[j];
                 }
             }
         }
@@ -227,7 +244,13 @@ int small_conv_in_launch(const SmallConvInArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)a.Cout * 9 * a.Cin * sizeof(half_t);
     if (lds > 64 * 1024) return LD_ERR_SHAPE;
     const long long total = (long long)a.N * a.H * a.W * (a.Cout >> 3);
-    hipLaunchKernelGGL(small_conv_in_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), lds, stream, a);
+    const dim3 grid(grid_for(total, 256, 1024));
+    switch (a.Cin) {
+        case 1: hipLaunchKernelGGL(small_conv_in_kernel<1>, grid, dim3(256), lds, stream, a); break;
+        case 2: hipLaunchKernelGGL(small_conv_in_kernel<2>, grid, dim3(256), lds, stream, a); break;
+        case 3: hipLaunchKernelGGL(small_conv_in_kernel<3>, grid, dim3(256), lds, stream, a); break;
+        default: hipLaunchKernelGGL(small_conv_in_kernel<4>, grid, dim3(256), lds, stream, a); break;
+    }
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
 

@@ -10,7 +10,7 @@
 namespace {
 
 constexpr int GN_THREADS = 256;
-constexpr int GN_MAX_SLOTS = 2;   // channel chunks per thread: supports C <= 2 * 256 * 8 = 4096
+constexpr int GN_SLABS = 4;       // channel slabs of 8 groups each: grid.z
 
 struct GnArgs {
     const half_t* x1;
@@ -29,33 +29,25 @@ __device__ __forceinline__ const half_t* gn_src(const GnArgs& a, int n, int pix,
                     : a.x2 + ((long long)n * a.HW + pix) * a.C2 + (c - a.C1);
 }
 
+// Block = (pixel chunk, image, slab of 8 groups = C/4 channels = C/32 16-byte chunks).  A thread owns ONE 8-channel
+// chunk (fixed over its pixel loop, so scale/shift live in registers) and strides over the pixels of the chunk.
+// No float atomics: every LDS slot has one writer and the reductions run in a fixed order (bitwise reproducible).
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
-    // per-(pixel-lane, channel) partial sums, each slot written by exactly one thread; reduced in a fixed order
-    // (no float atomics: bitwise reproducible run to run)
-    __shared__ float csum[4096], csq[4096];
-    const int C = a.C1 + a.C2, CH = C >> 3, cpg = C / 32;
-    const int n = blockIdx.y, pc = blockIdx.x, tid = threadIdx.x;
-    const int rows_par = CH >= GN_THREADS ? 1 : GN_THREADS / CH;
+    __shared__ float csum[2048], csq[2048];   // [rows_par][slab channels], rows_par * CS <= 256 * 8
+    const int C = a.C1 + a.C2, cpg = C / 32;
+    const int CS = C / GN_SLABS, CHS = CS >> 3;                 // slab channels / chunks
+    const int n = blockIdx.y, pc = blockIdx.x, slab = blockIdx.z, tid = threadIdx.x;
+    const int rows_par = GN_THREADS / CHS;
+    const int cc = tid % CHS, prow = tid / CHS;
+    const int c0 = slab * CS + cc * 8;
     const int p_begin = pc * a.ppb, p_end = min(a.HW, p_begin + a.ppb);
-#pragma unroll
-    for (int slot = 0; slot < GN_MAX_SLOTS; ++slot) {
-        int cc, prow;
-        if (CH >= GN_THREADS) {
-            cc = tid + slot * GN_THREADS;
-            prow = 0;
-            if (cc >= CH) break;
-        } else {
-            if (slot > 0) break;
-            cc = tid % CH;
-            prow = tid / CH;
-            if (prow >= rows_par) break;
-        }
+    if (prow < rows_par) {
         float s[8], ss[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
         for (int pix = p_begin + prow; pix < p_end; pix += rows_par) {
             float v[8];
-            unpack8(ld16(gn_src(a, n, pix, cc * 8)), v);
+            unpack8(ld16(gn_src(a, n, pix, c0)), v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 s[j] += v[j];
@@ -64,27 +56,27 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            csum[prow * C + cc * 8 + j] = s[j];      // rows_par * C <= 4096
-            csq[prow * C + cc * 8 + j] = ss[j];
+            csum[prow * CS + cc * 8 + j] = s[j];
+            csq[prow * CS + cc * 8 + j] = ss[j];
         }
     }
     __syncthreads();
     {
-        const int g = tid >> 3, sub = tid & 7;
+        const int g = tid >> 5, sub = tid & 31;                  // 8 groups x 32 lanes
         const int cnt = rows_par * cpg;
         float s = 0.f, ss = 0.f;
-        for (int i = sub; i < cnt; i += 8) {
+        for (int i = sub; i < cnt; i += 32) {
             const int pr = i / cpg, c = g * cpg + (i - pr * cpg);
-            s += csum[pr * C + c];
-            ss += csq[pr * C + c];
+            s += csum[pr * CS + c];
+            ss += csq[pr * CS + c];
         }
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
+        for (int o = 1; o < 32; o <<= 1) {
             s += __shfl_xor(s, o, 64);
             ss += __shfl_xor(ss, o, 64);
         }
         if (sub == 0) {
-            float* o = a.partial + (((long long)n * a.P + pc) * 32 + g) * 2;
+            float* o = a.partial + (((long long)n * a.P + pc) * 32 + slab * 8 + g) * 2;
             o[0] = s;
             o[1] = ss;
         }
@@ -92,19 +84,20 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
-    __shared__ float mean[32], rstd[32];
-    const int C = a.C1 + a.C2, CH = C >> 3, cpg = C / 32;
-    const int n = blockIdx.y, pc = blockIdx.x, tid = threadIdx.x;
-    {   // finish the statistics: 8 lanes per group sweep the P partial slabs in a fixed order
-        const int g = tid >> 3, sub = tid & 7;
+    __shared__ float mean[8], rstd[8];
+    const int C = a.C1 + a.C2, cpg = C / 32;
+    const int CS = C / GN_SLABS, CHS = CS >> 3;
+    const int n = blockIdx.y, pc = blockIdx.x, slab = blockIdx.z, tid = threadIdx.x;
+    {   // finish the statistics of this slab's 8 groups: 32 lanes per group sweep the P partial slabs in a fixed order
+        const int g = tid >> 5, sub = tid & 31;
         float s = 0.f, ss = 0.f;
-        const float* pp = a.partial + ((long long)n * a.P * 32 + g) * 2;
-        for (int i = sub; i < a.P; i += 8) {
+        const float* pp = a.partial + ((long long)n * a.P * 32 + slab * 8 + g) * 2;
+        for (int i = sub; i < a.P; i += 32) {
             s += pp[(long long)i * 64];
             ss += pp[(long long)i * 64 + 1];
         }
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
+        for (int o = 1; o < 32; o <<= 1) {
             s += __shfl_xor(s, o, 64);
             ss += __shfl_xor(ss, o, 64);
         }
@@ -117,40 +110,29 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
         }
     }
     __syncthreads();
-    const int rows_par = CH >= GN_THREADS ? 1 : GN_THREADS / CH;
+    const int rows_par = GN_THREADS / CHS;
+    const int cc = tid % CHS, prow = tid / CHS;
+    if (prow >= rows_par) return;
+    const int c0 = slab * CS + cc * 8;
     const int p_begin = pc * a.ppb, p_end = min(a.HW, p_begin + a.ppb);
+    float ga[8], be[8], sc[8], sh[8];
+    unpack8(ld16(a.gamma + c0), ga);
+    unpack8(ld16(a.beta + c0), be);
 #pragma unroll
-    for (int slot = 0; slot < GN_MAX_SLOTS; ++slot) {
-        int cc, prow;
-        if (CH >= GN_THREADS) {
-            cc = tid + slot * GN_THREADS;
-            prow = 0;
-            if (cc >= CH) break;
-        } else {
-            if (slot > 0) break;
-            cc = tid % CH;
-            prow = tid / CH;
-            if (prow >= rows_par) break;
-        }
-        float ga[8], be[8], sc[8], sh[8];
-        unpack8(ld16(a.gamma + cc * 8), ga);
-        unpack8(ld16(a.beta + cc * 8), be);
+    for (int j = 0; j < 8; ++j) {
+        const int g = (cc * 8 + j) / cpg;                        // group within the slab
+        sc[j] = rstd[g] * ga[j];
+        sh[j] = be[j] - mean[g] * sc[j];
+    }
+    for (int pix = p_begin + prow; pix < p_end; pix += rows_par) {
+        float v[8];
+        unpack8(ld16(gn_src(a, n, pix, c0)), v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int g = (cc * 8 + j) / cpg;
-            sc[j] = rstd[g] * ga[j];
-            sh[j] = be[j] - mean[g] * sc[j];
+            v[j] = v[j] * sc[j] + sh[j];
+            if (a.silu) v[j] = silu_f(v[j]);
         }
-        for (int pix = p_begin + prow; pix < p_end; pix += rows_par) {
-            float v[8];
-            unpack8(ld16(gn_src(a, n, pix, cc * 8)), v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v[j] = v[j] * sc[j] + sh[j];
-                if (a.silu) v[j] = silu_f(v[j]);
-            }
-            st16(a.y + ((long long)n * a.HW + pix) * C + cc * 8, pack8(v));
-        }
+        st16(a.y + ((long long)n * a.HW + pix) * C + c0, pack8(v));
     }
 }
 
@@ -242,7 +224,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ 
 }  // namespace
 
 size_t groupnorm_workspace_bytes(int n_img, int HW) {
-    const int P = gn_num_chunks(HW);
+    const int P = gn_num_chunks(n_img, HW);
     return (size_t)n_img * P * 32 * 2 * sizeof(float);
 }
 
@@ -250,13 +232,13 @@ int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_i
                      const half_t* beta, float eps, int silu, half_t* y, float* partial, hipStream_t stream) {
     const int C = C1 + C2;
     if (x1 == nullptr || y == nullptr || partial == nullptr || gamma == nullptr || beta == nullptr) return LD_ERR_ARG;
-    if (C % 32 || C1 % 8 || C2 % 8 || C > 4096 || C1 <= 0 || (C2 > 0 && x2 == nullptr)) return LD_ERR_SHAPE;
+    if (C % 32 || C1 % 8 || C2 % 8 || C > 8192 || C1 <= 0 || (C2 > 0 && x2 == nullptr)) return LD_ERR_SHAPE;
     GnArgs a;
     a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.HW = HW;
-    a.P = gn_num_chunks(HW);
+    a.P = gn_num_chunks(n_img, HW);
     a.ppb = (HW + a.P - 1) / a.P;
     a.partial = partial; a.gamma = gamma; a.beta = beta; a.y = y; a.eps = eps; a.silu = silu;
-    dim3 grid(a.P, n_img);
+    dim3 grid(a.P, n_img, GN_SLABS);
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, stream, a);
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), 0, stream, a);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;

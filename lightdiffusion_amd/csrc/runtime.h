@@ -3,6 +3,8 @@
 // so a whole forward can be captured into a hipGraph), and an Exec context that counts launches / FLOPs and
 // doubles as a dry-run planner (sizes the arena without touching the GPU).
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -101,6 +103,8 @@ enum KClass { KC_CONV3 = 0, KC_GEMM = 1, KC_ATTN = 2, KC_GNORM = 3, KC_LNORM = 4
 struct Timing {
     std::vector<hipEvent_t> ev;     // pool, pairs (start, stop)
     std::vector<int> cls;
+    std::vector<std::string> desc;   // per launch, only when LD_PROFILE_DUMP is set
+    bool verbose = false;
     size_t used = 0;
     double ms[KC_COUNT] = {0}, flops[KC_COUNT] = {0};
     int launches[KC_COUNT] = {0};
@@ -115,6 +119,8 @@ struct Timing {
     void reset() {
         used = 0;
         cls.clear();
+        desc.clear();
+        verbose = getenv("LD_PROFILE_DUMP") != nullptr;
         for (int i = 0; i < KC_COUNT; ++i) ms[i] = flops[i] = 0, launches[i] = 0;
     }
     void collect() {
@@ -122,6 +128,7 @@ struct Timing {
             float t = 0.f;
             (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]);
             ms[cls[i / 2]] += t;
+            if (verbose && i / 2 < desc.size()) fprintf(stderr, "[ld_profile] %8.1f us  %s\n", t * 1e3, desc[i / 2].c_str());
         }
     }
     void destroy() {
@@ -146,9 +153,14 @@ struct Exec {
     }
     bool overflow() const { return !dry && arena->peak > arena->cap; }
 
-    void t_begin(int c, double fl, int nl) {
+    void t_begin(int c, double fl, int nl, const char* what = "", long long a = 0, long long b = 0, long long d = 0, long long e = 0) {
         if (timing == nullptr || dry) return;
         timing->cls.push_back(c);
+        if (timing->verbose) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "%-10s %8lld %6lld %6lld %4lld  %.2f GFLOP", what, a, b, d, e, fl * 1e-9);
+            timing->desc.push_back(buf);
+        }
         timing->flops[c] += fl;
         timing->launches[c] += nl;
         (void)hipEventRecord(timing->next(), stream);
@@ -167,7 +179,8 @@ struct Exec {
         }
         launches += 1;
         if (dry || status != LD_OK) return;
-        t_begin(p.conv && p.ksize == 3 ? KC_CONV3 : KC_GEMM, fl, 1);
+        t_begin(p.conv && p.ksize == 3 ? KC_CONV3 : KC_GEMM, fl, 1, p.conv ? (p.ksize == 3 ? "conv3" : "conv1") : (p.act == 2 ? "geglu" : "gemm"),
+                p.M, p.N, p.K, p.batch);
         note(gemm_launch(p, stream));
         t_end();
     }
@@ -176,14 +189,14 @@ struct Exec {
         const size_t m = arena->mark();
         float* ws = reinterpret_cast<float*>(arena->alloc(groupnorm_workspace_bytes(n, HW)));
         launches += 2;
-        t_begin(KC_GNORM, 0.0, 2);
+        t_begin(KC_GNORM, 0.0, 2, "groupnorm", n, HW, C1 + C2, silu);
         if (!dry && status == LD_OK) note(groupnorm_launch(x1, C1, x2, C2, n, HW, g, b, eps, silu, y, ws, stream));
         t_end();
         arena->release(m);
     }
     void layernorm(const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int C) {
         launches += 1;
-        t_begin(KC_LNORM, 0.0, 1);
+        t_begin(KC_LNORM, 0.0, 1, "layernorm", rows, C);
         if (!dry && status == LD_OK) note(layernorm_launch(x, g, b, y, rows, C, 1e-5f, stream));
         t_end();
     }
@@ -191,7 +204,7 @@ struct Exec {
         const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.d;
         flops += fl;
         launches += 1;
-        t_begin(KC_ATTN, fl, 1);
+        t_begin(KC_ATTN, fl, 1, "attention", (long long)p.B * p.H, p.Lq, p.Lk, p.d);
         if (!dry && status == LD_OK) note(attention_launch(p, stream));
         t_end();
     }
