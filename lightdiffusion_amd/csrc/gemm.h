@@ -37,6 +37,7 @@ struct GemmParams {
     // ---- tiling controls (0 = auto)
     int bm = 0, bn = 0;          // bn must match the repack-time choice for GEGLU
     int splitk = 0;
+    int m_fastest = -1;          // tile order: -1 auto, 0 n fastest, 1 m fastest
     float* partial = nullptr;    // split-K workspace, >= splitk*M*N floats
     size_t partial_bytes = 0;
 };

@@ -8,6 +8,8 @@
 // output channels of one output row -> 8-byte LDS writes / 16-byte split-K stores in the epilogue.
 // Epilogue: accumulators -> fp16 tile in LDS -> row-wise 16-byte coalesced stores with the fused bias /
 // time-embedding broadcast / SiLU / GEGLU / residual.
+#include <cstdlib>
+
 #include "gemm.h"
 
 namespace {
@@ -47,6 +49,87 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int 
     st16(p.C + (long long)z * p.sC + (long long)m * p.ldc + n_out, pack8(v));
 }
 
+// Tile epilogue: the fp16 C tile sits in LDS; every thread owns EIT 16-byte chunks of it.  All global operands of the
+// fused epilogue (bias, time-embedding row vector, residual) are loaded FIRST for every chunk, then consumed: the
+// loads overlap each other instead of paying one full memory latency per chunk (the accumulators are dead here, so
+// the registers are free).
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t* Cs, int z, int m0, int n0, int tid) {
+    constexpr int CLD = BN + 8;
+    if (p.act == 2) {
+        constexpr int CPR = BN / 16;
+        constexpr int EIT = (BM * CPR + NT - 1) / NT;
+        uint4 rba[EIT], rbg[EIT], rres[EIT];
+#pragma unroll
+        for (int it = 0; it < EIT; ++it) {
+            const int q = tid + it * NT;
+            const int row = q / CPR, cc = q - row * CPR;
+            const int m = m0 + row, nv = n0 + cc * 8, ng = nv + BN / 2;
+            const bool ok = q < BM * CPR && m < p.M && ng < p.N;
+            rba[it] = ok ? ld16(p.bias_n + nv) : zero16();
+            rbg[it] = ok ? ld16(p.bias_n + ng) : zero16();
+            rres[it] = (ok && p.R != nullptr) ? ld16(p.R + (long long)z * p.sR + (long long)m * p.ldr + n0 / 2 + cc * 8) : zero16();
+        }
+#pragma unroll
+        for (int it = 0; it < EIT; ++it) {
+            const int q = tid + it * NT;
+            const int row = q / CPR, cc = q - row * CPR;
+            const int m = m0 + row, ng = n0 + cc * 8 + BN / 2;
+            if (q < BM * CPR && m < p.M && ng < p.N) {
+                float a[8], g[8], ba[8], bg[8], r[8];
+                unpack8(ld16(Cs + row * CLD + cc * 8), a);
+                unpack8(ld16(Cs + row * CLD + BN / 2 + cc * 8), g);
+                unpack8(rba[it], ba);
+                unpack8(rbg[it], bg);
+                unpack8(rres[it], r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = (a[j] + ba[j]) * gelu_f(g[j] + bg[j]) + r[j];
+                st16(p.C + (long long)z * p.sC + (long long)m * p.ldc + n0 / 2 + cc * 8, pack8(a));
+            }
+        }
+    } else {
+        constexpr int CPR = BN / 8;
+        constexpr int EIT = (BM * CPR + NT - 1) / NT;
+        constexpr int GRP = EIT > 5 ? (EIT + 1) / 2 : EIT;   // two passes for the big tiles: bounds the live registers
+        const bool hb = p.bias_n != nullptr, hv = p.rowvec != nullptr, hr = p.R != nullptr;
+#pragma unroll
+        for (int g0 = 0; g0 < EIT; g0 += GRP) {
+            uint4 rb[GRP], rv[GRP], rres[GRP];
+#pragma unroll
+            for (int k = 0; k < GRP; ++k) {
+                const int q = tid + (g0 + k) * NT;
+                const int row = q / CPR, cc = q - row * CPR;
+                const int m = m0 + row, n = n0 + cc * 8;
+                const bool ok = (g0 + k) < EIT && q < BM * CPR && m < p.M && n < p.N;
+                rb[k] = (ok && hb) ? ld16(p.bias_n + n) : zero16();
+                rv[k] = (ok && hv) ? ld16(p.rowvec + (long long)(m / p.rows_per_vec) * p.ldrv + n) : zero16();
+                rres[k] = (ok && hr) ? ld16(p.R + (long long)z * p.sR + (long long)m * p.ldr + n) : zero16();
+            }
+#pragma unroll
+            for (int k = 0; k < GRP; ++k) {
+                const int q = tid + (g0 + k) * NT;
+                const int row = q / CPR, cc = q - row * CPR;
+                const int m = m0 + row, n = n0 + cc * 8;
+                if ((g0 + k) < EIT && q < BM * CPR && m < p.M && n < p.N) {
+                    float v[8], b[8], e[8], r[8];
+                    unpack8(ld16(Cs + row * CLD + cc * 8), v);
+                    unpack8(rb[k], b);
+                    unpack8(rv[k], e);
+                    unpack8(rres[k], r);
+                    const float bm = p.bias_m != nullptr ? (float)p.bias_m[m] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float t = v[j] + b[j] + bm + e[j];
+                        if (p.act == 1) t = silu_f(t);
+                        v[j] = t + r[j];
+                    }
+                    st16(p.C + (long long)z * p.sC + (long long)m * p.ldc + n, pack8(v));
+                }
+            }
+        }
+    }
+}
+
 template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile
@@ -68,8 +151,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     int bid = xcd_remap(blockIdx.x, tiles * splitk);
     const int ks = bid / tiles;
     bid -= ks * tiles;
-    // n fastest: consecutive blocks (one XCD) sweep the N tiles of one M panel -> A panel stays in that L2
-    const int tn_i = bid % tiles_n, tm_i = bid / tiles_n;
+    // n fastest: consecutive blocks (one XCD) sweep the N tiles of one M panel -> A panel stays in that L2;
+    // m fastest: they sweep the M tiles of one weight panel (chosen on the host by streamed bytes)
+    const int tn_i = p.m_fastest ? bid / tiles_m : bid % tiles_n;
+    const int tm_i = p.m_fastest ? bid % tiles_m : bid / tiles_n;
     const int m0 = tm_i * BM, n0 = tn_i * BN;
 
     const int KT = (p.K + BK - 1) / BK;
@@ -239,35 +324,288 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
     }
     __syncthreads();
 
-    if (p.act == 2) {
-        constexpr int CPR = BN / 16;   // output chunks per row (BN/2 columns)
-        for (int q = tid; q < BM * CPR; q += NT) {
-            const int row = q / CPR, cc = q - row * CPR;
-            const int m = m0 + row;
-            const int nv = n0 + cc * 8, ng = nv + BN / 2;
-            if (m < p.M && ng < p.N) {
-                float a[8], g[8], ba[8], bg[8];
-                unpack8(ld16(Cs + row * CLD + cc * 8), a);
-                unpack8(ld16(Cs + row * CLD + BN / 2 + cc * 8), g);
-                unpack8(ld16(p.bias_n + nv), ba);
-                unpack8(ld16(p.bias_n + ng), bg);
+    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid);
+}
+
+// =====================================================================================================================
+// v2 main loop: direct global->LDS loads (global_load_lds_dwordx4) into a 4-stage ring, 3 K-slabs (BK = 32) in flight
+// behind a COUNTED vmcnt and ONE raw s_barrier per K-step; no staging registers, no ds_write, address generation hoisted
+// out of the loop (pointers advance by a constant; conv tap / concat-source changes are a rare wave-uniform branch).
+// LDS rows are 64 B (4 chunks of 16 B); the DMA writes lane-linear, so the bank swizzle is applied to the SOURCE chunk
+// and to the fragment read alike (guide rule 21): physical chunk = logical chunk ^ SWZ[(row >> 2) & 3], SWZ = {0,2,3,1},
+// which makes every ds_read_b128 lane group of the 16x16x32 fragment reads hit 16 distinct 16-byte slots.
+// =====================================================================================================================
+__device__ uint4 g_zero_page[8];   // 128 zero bytes: the source of padded / out-of-range chunks
+
+__device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+
+// One LDS-DMA wave-instruction: lane l copies 16 bytes from its own global address to LDS byte (lds_base + 16*l).
+// Issued through inline asm on purpose: hipcc's waitcnt pass does not see it, so it does not force vmcnt(0) before the
+// fragment reads of OTHER ring stages (with the builtin it does, draining the ring every K-step).  The counted
+// s_waitcnt vmcnt(N) + s_barrier in the loop are the only ordering (cdna guide §5.7: M0 is set and restored inside the
+// same statement; lds_base must be wave-uniform).
+__device__ __forceinline__ void glds16(const half_t* src, unsigned lds_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(src), "s"(lds_base)
+        : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const half_t* p) {
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GemmParams p) {
+    constexpr int BK2 = 32, NST = 4, PF = 3;
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_CH = BM * 4, B_CH = BN * 4;                 // 16-byte chunks per stage
+    constexpr int A_IT = A_CH / NT;                             // 2 (BM=128) or 1 (BM=64)
+    constexpr int B_FULL = B_CH / NT;                           // B instructions every wave issues
+    constexpr bool B_TAIL = (B_CH % NT) != 0;                   // + one more for waves 0,1 (BN = 160)
+    constexpr int STAGE = (BM + BN) * BK2;                      // halfs per stage
+    constexpr int CLD = BN + 8;
+    static_assert(BM * CLD <= NST * STAGE, "epilogue tile must fit in the ring");
+    static_assert(!B_TAIL || (B_CH % NT) == NT / 2, "tail = exactly waves 0 and 1");
+    __shared__ __attribute__((aligned(16))) half_t smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
+    const int z = blockIdx.z;
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles = tiles_m * tiles_n;
+    const int splitk = p.splitk > 1 ? p.splitk : 1;
+    int bid = xcd_remap(blockIdx.x, tiles * splitk);
+    const int ks = bid / tiles;
+    bid -= ks * tiles;
+    const int tn_i = p.m_fastest ? bid / tiles_m : bid % tiles_n;
+    const int tm_i = p.m_fastest ? bid % tiles_m : bid / tiles_n;
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+
+    const int KT = (p.K + BK2 - 1) / BK2;
+    const int kt_begin = (int)((long long)ks * KT / splitk), kt_end = (int)((long long)(ks + 1) * KT / splitk);
+
+    const half_t* Ab = p.A + (long long)z * p.sA;
+    const half_t* Wb = p.W + (long long)z * p.sW;
+    const half_t* zp = reinterpret_cast<const half_t*>(g_zero_page);
+    const int Cin = p.C1 + p.C2;
+
+    // ---- loader state.  Thread owns physical chunk q = tid + i*NT of the A tile: row = q >> 2, slot = q & 3, and
+    // fetches the LOGICAL chunk lc = slot ^ swz(row) of that row from global memory.
+    int a_lc[A_IT];
+    bool a_ok[A_IT];
+    int a_img[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+    const half_t* a_ptr[A_IT];      // current source of this thread's chunk (valid or not)
+    bool a_val[A_IT];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a[j] = (a[j] + ba[j]) * gelu_f(g[j] + bg[j]);
-                epilogue_store8(p, z, m, n0 / 2 + cc * 8, 0, a);
-            }
-        }
-    } else {
-        constexpr int CPR = BN / 8;
-        for (int q = tid; q < BM * CPR; q += NT) {
-            const int row = q / CPR, cc = q - row * CPR;
-            const int m = m0 + row, n = n0 + cc * 8;
-            if (m < p.M && n < p.N) {
-                float v[8];
-                unpack8(ld16(Cs + row * CLD + cc * 8), v);
-                epilogue_store8(p, z, m, n, n, v);
-            }
+    for (int i = 0; i < A_IT; ++i) {
+        const int q = tid + i * NT;
+        const int row = q >> 2;
+        a_lc[i] = (q & 3) ^ swz4(row);
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        a_img[i] = a_iy0[i] = a_ix0[i] = 0;
+        a_ptr[i] = zp;
+        a_val[i] = false;
+        if (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int mm = a_ok[i] ? m : 0;
+            const int img = mm / hw, rem = mm - img * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_img[i] = img;
+            a_iy0[i] = oy * p.stride - (p.ksize >> 1);
+            a_ix0[i] = ox * p.stride - (p.ksize >> 1);
+        } else {
+            a_ptr[i] = Ab + (long long)(a_ok[i] ? m : 0) * p.lda + a_lc[i] * 8;
         }
     }
+    // conv: (re)compute the pointers for the K position k0 (start of a tap/source segment or of the split)
+    int seg_left = 0;   // K-steps until the next segment boundary (conv only)
+    auto conv_seek = [&](int k0) {
+        const int tap = k0 / Cin;
+        const int c0 = k0 - tap * Cin;
+        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+        const bool second = c0 >= p.C1;
+        const half_t* src = second ? p.A2 : Ab;
+        const int Cs = second ? p.C2 : p.C1;
+        const int cl = second ? c0 - p.C1 : c0;
+        seg_left = ((second ? Cin : p.C1) - c0) / BK2;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv && tap < p.ksize * p.ksize;
+            int sy = iy, sx = ix;
+            if (p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws) {
+                sy = iy >> 1;
+                sx = ix >> 1;
+            } else if (p.Hv != p.Hs || p.Wv != p.Ws) {
+                sy = (int)((long long)iy * p.Hs / p.Hv);
+                sx = (int)((long long)ix * p.Ws / p.Wv);
+            }
+            a_val[i] = ok;
+            a_ptr[i] = ok ? src + (((long long)a_img[i] * p.Hs + sy) * p.Ws + sx) * Cs + cl + a_lc[i] * 8 : zp;
+        }
+    };
+
+    // B (weights): chunk q -> row = q >> 2
+    constexpr int B_IT = B_FULL + (B_TAIL ? 1 : 0);
+    const half_t* b_ptr[B_IT];
+    bool b_ok[B_IT];
+    int b_lc[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int q = tid + i * NT;
+        const int row = q >> 2;
+        b_lc[i] = (q & 3) ^ swz4(row);
+        b_ok[i] = (q < B_CH) && (n0 + row < p.n_valid);
+        b_ptr[i] = Wb + (long long)(b_ok[i] ? n0 + row : 0) * p.ldw + b_lc[i] * 8;
+    }
+    const bool tail_wave = B_TAIL && wid < 2;
+
+    // issue the loads of K-slab kt into ring stage `st` (every wave issues the same number of instructions per slab)
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    auto issue = [&](int kt, int st) {
+        const unsigned As = smem_base + (unsigned)(st * STAGE) * 2u;     // byte addresses in LDS, wave-uniform
+        const unsigned Bs = As + (unsigned)(BM * BK2) * 2u;
+        const bool live = kt < kt_end;
+        const int k0 = kt * BK2;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const half_t* src;
+            if (CONV) src = (live && a_val[i]) ? a_ptr[i] : zp;
+            else src = (live && a_ok[i] && k0 + a_lc[i] * 8 < p.K) ? a_ptr[i] : zp;
+            glds16(src, As + (unsigned)(i * NT + wid * 64) * 16u);
+        }
+#pragma unroll
+        for (int i = 0; i < B_FULL; ++i) {
+            const half_t* src = (live && b_ok[i] && k0 + b_lc[i] * 8 < p.K) ? b_ptr[i] : zp;
+            glds16(src, Bs + (unsigned)(i * NT + wid * 64) * 16u);
+        }
+        if (B_TAIL && tail_wave) {
+            const half_t* src = (live && b_ok[B_IT - 1] && k0 + b_lc[B_IT - 1] * 8 < p.K) ? b_ptr[B_IT - 1] : zp;
+            glds16(src, Bs + (unsigned)(B_FULL * NT + wid * 64) * 16u);
+        }
+        // advance to the next K-slab
+        if (CONV) {
+            if (--seg_left <= 0) {
+                conv_seek(k0 + BK2);
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) a_ptr[i] += a_val[i] ? BK2 : 0;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) a_ptr[i] += BK2;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) b_ptr[i] += BK2;
+    };
+
+    // position the loaders at the split's first slab
+    if (CONV) {
+        conv_seek(kt_begin * BK2);
+    } else {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) a_ptr[i] += (long long)kt_begin * BK2;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) b_ptr[i] += (long long)kt_begin * BK2;
+
+    // ---- fragment read offsets (halfs, within a stage)
+    const int fr = lane & 15, fq = lane >> 4;
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wm0 + i * 16 + fr;
+        a_off[i] = row * BK2 + ((fq ^ swz4(row)) << 3);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = wn0 + j * 16 + fr;
+        b_off[j] = BM * BK2 + row * BK2 + ((fq ^ swz4(row)) << 3);
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: PF slabs in flight
+#pragma unroll
+    for (int t = 0; t < PF; ++t) issue(kt_begin + t, t);
+
+    constexpr int LPT_HI = A_IT + B_IT;          // loads per slab, waves 0-1
+    constexpr int LPT_LO = A_IT + B_FULL;        // waves 2-3
+    int st = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        // slab kt has landed for this wave once all but the youngest PF-1 slabs' loads are done
+        if (B_TAIL && tail_wave) wait_vmcnt<LPT_HI * (PF - 1)>();
+        else wait_vmcnt<LPT_LO * (PF - 1)>();
+        __builtin_amdgcn_s_barrier();            // ... for every wave; and every wave has finished reading slab kt-1
+        issue(kt + PF, (st + PF) & (NST - 1));   // refill the stage slab kt-1 occupied
+        const half_t* S = smem + st * STAGE;
+        half8 bf[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = as_half8(ld16(S + b_off[j]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const half8 af = as_half8(ld16(S + a_off[i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af, acc[i][j], 0, 0, 0);
+        }
+        st = (st + 1) & (NST - 1);
+    }
+    wait_vmcnt<0>();                             // drain the look-ahead (zero-page) loads before the ring is reused
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue (identical to v1)
+    if (splitk > 1) {
+        float* part = p.partial + (long long)ks * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm0 + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn0 + j * 16 + fq * 4;
+                if (m < p.M && n < p.N) {
+                    f32x4 v = acc[i][j];
+                    v *= p.alpha;
+                    *reinterpret_cast<f32x4*>(part + (long long)m * p.N + n) = v;
+                }
+            }
+        }
+        return;
+    }
+    half_t* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm0 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn0 + j * 16 + fq * 4;
+            half4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] * p.alpha);
+            *reinterpret_cast<half4*>(Cs + ml * CLD + nl) = h;
+        }
+    }
+    __syncthreads();
+    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid);
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue
@@ -316,15 +654,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     }
 }
 
+bool use_v1() {
+    static const bool v = getenv("LD_GEMM_V1") != nullptr;
+    return v;
+}
+
 template <int BM, int BN>
 void launch_cfg(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int sk = p.splitk > 1 ? p.splitk : 1;
     dim3 grid(tiles * sk, 1, p.batch), block(NT);
-    if (p.conv)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, block, 0, s, p);
-    else
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, block, 0, s, p);
+    if (use_v1()) {
+        if (p.conv)
+            hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, block, 0, s, p);
+    } else {
+        if (p.conv)
+            hipLaunchKernelGGL((gemm2_kernel<BM, BN, true>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((gemm2_kernel<BM, BN, false>), grid, block, 0, s, p);
+    }
 }
 
 }  // namespace
@@ -355,7 +705,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (bm == 0) bm = (((p.M + 127) / 128) * tiles_n * p.batch >= 256) ? 128 : 64;
     if (bm != 64 && bm != 128) return LD_ERR_ARG;
     const int tiles = ((p.M + bm - 1) / bm) * tiles_n;
-    const int KT = (p.K + BK - 1) / BK;
+    const int KT = (p.K + BK - 1) / BK;          // 64-wide units (v2 slabs are 32 wide: twice as many, same split points)
 
     int sk = p.splitk;
     if (sk == 0) {   // auto: fill ~2 blocks per CU when the tile grid alone cannot
@@ -374,6 +724,11 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     }
     p.splitk = sk;
     p.bn = bn;
+    static const char* order_env = getenv("LD_GEMM_ORDER");      // debugging / A-B: "n", "m" or unset (auto)
+    if (order_env != nullptr && (order_env[0] == 'n' || order_env[0] == 'm')) p.m_fastest = order_env[0] == 'm';
+    // measured (profiles/r01_b): n-fastest wins on every SD1.5 shape — the 9 taps of a 3x3 conv and the N tiles of one
+    // M panel re-read the same activations through the XCD's L2, which matters more than re-streaming the weights
+    if (p.m_fastest < 0) p.m_fastest = 0;
 
     if (bm == 128 && bn == 160) launch_cfg<128, 160>(p, stream);
     else if (bm == 128 && bn == 128) launch_cfg<128, 128>(p, stream);
