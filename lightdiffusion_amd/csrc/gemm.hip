@@ -345,14 +345,13 @@ __device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3)
 // s_waitcnt vmcnt(N) + s_barrier in the loop are the only ordering (cdna guide §5.7: M0 is set and restored inside the
 // same statement; lds_base must be wave-uniform).
 __device__ __forceinline__ void glds16(const half_t* src, unsigned lds_base) {
-    unsigned keep;
+    // M0 is written and consumed inside the statement; nothing else in these kernels reads M0 (gfx9+ DS instructions do
+    // not), so it is not restored — two scalar instructions less per DMA in an issue-bound loop.
     asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
+        "global_load_lds_dwordx4 %0, off"
+        :
         : "v"(src), "s"(lds_base)
         : "memory");
 }
@@ -435,6 +434,7 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GemmParams p) {
     }
     // conv: (re)compute the pointers for the K position k0 (start of a tap/source segment or of the split)
     int seg_left = 0;   // K-steps until the next segment boundary (conv only)
+    int a_step[A_IT];   // per-slab pointer stride with validity folded in (0 = parked on the zero page)
     auto conv_seek = [&](int k0) {
         const int tap = k0 / Cin;
         const int c0 = k0 - tap * Cin;
@@ -458,6 +458,7 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GemmParams p) {
             }
             a_val[i] = ok;
             a_ptr[i] = ok ? src + (((long long)a_img[i] * p.Hs + sy) * p.Ws + sx) * Cs + cl + a_lc[i] * 8 : zp;
+            a_step[i] = ok ? BK2 : 0;
         }
     };
 
@@ -476,28 +477,52 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GemmParams p) {
     }
     const bool tail_wave = B_TAIL && wid < 2;
 
+    // K tail (K % 32 != 0, plain mode only) needs a per-chunk bound check; SD1.5 shapes never do.
+    const bool ktail = !CONV && (p.K % BK2) != 0;
+    // per-slab pointer strides with the row validity folded in: invalid rows sit on the zero page and do not move
+    int b_step[B_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        if (!CONV) {
+            if (!a_ok[i]) a_ptr[i] = zp;
+            a_step[i] = a_ok[i] ? BK2 : 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        if (!b_ok[i]) b_ptr[i] = zp;
+        b_step[i] = b_ok[i] ? BK2 : 0;
+    }
+
     // issue the loads of K-slab kt into ring stage `st` (every wave issues the same number of instructions per slab)
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     auto issue = [&](int kt, int st) {
         const unsigned As = smem_base + (unsigned)(st * STAGE) * 2u;     // byte addresses in LDS, wave-uniform
         const unsigned Bs = As + (unsigned)(BM * BK2) * 2u;
-        const bool live = kt < kt_end;
         const int k0 = kt * BK2;
+        if (kt >= kt_end) {
+            // look-ahead past the split's last slab: same number of DMAs (keeps the vmcnt arithmetic uniform), all from
+            // the zero page; wave-uniform branch, no per-lane selects in the steady state below
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const half_t* src;
-            if (CONV) src = (live && a_val[i]) ? a_ptr[i] : zp;
-            else src = (live && a_ok[i] && k0 + a_lc[i] * 8 < p.K) ? a_ptr[i] : zp;
-            glds16(src, As + (unsigned)(i * NT + wid * 64) * 16u);
-        }
+            for (int i = 0; i < A_IT; ++i) glds16(zp, As + (unsigned)(i * NT + wid * 64) * 16u);
 #pragma unroll
-        for (int i = 0; i < B_FULL; ++i) {
-            const half_t* src = (live && b_ok[i] && k0 + b_lc[i] * 8 < p.K) ? b_ptr[i] : zp;
-            glds16(src, Bs + (unsigned)(i * NT + wid * 64) * 16u);
+            for (int i = 0; i < B_FULL; ++i) glds16(zp, Bs + (unsigned)(i * NT + wid * 64) * 16u);
+            if (B_TAIL && tail_wave) glds16(zp, Bs + (unsigned)(B_FULL * NT + wid * 64) * 16u);
+            return;
         }
-        if (B_TAIL && tail_wave) {
-            const half_t* src = (live && b_ok[B_IT - 1] && k0 + b_lc[B_IT - 1] * 8 < p.K) ? b_ptr[B_IT - 1] : zp;
-            glds16(src, Bs + (unsigned)(B_FULL * NT + wid * 64) * 16u);
+        if (ktail) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) glds16((k0 + a_lc[i] * 8 < p.K) ? a_ptr[i] : zp, As + (unsigned)(i * NT + wid * 64) * 16u);
+#pragma unroll
+            for (int i = 0; i < B_FULL; ++i) glds16((k0 + b_lc[i] * 8 < p.K) ? b_ptr[i] : zp, Bs + (unsigned)(i * NT + wid * 64) * 16u);
+            if (B_TAIL && tail_wave)
+                glds16((k0 + b_lc[B_IT - 1] * 8 < p.K) ? b_ptr[B_IT - 1] : zp, Bs + (unsigned)(B_FULL * NT + wid * 64) * 16u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) glds16(a_ptr[i], As + (unsigned)(i * NT + wid * 64) * 16u);
+#pragma unroll
+            for (int i = 0; i < B_FULL; ++i) glds16(b_ptr[i], Bs + (unsigned)(i * NT + wid * 64) * 16u);
+            if (B_TAIL && tail_wave) glds16(b_ptr[B_IT - 1], Bs + (unsigned)(B_FULL * NT + wid * 64) * 16u);
         }
         // advance to the next K-slab
         if (CONV) {
@@ -505,14 +530,14 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GemmParams p) {
                 conv_seek(k0 + BK2);
             } else {
 #pragma unroll
-                for (int i = 0; i < A_IT; ++i) a_ptr[i] += a_val[i] ? BK2 : 0;
+                for (int i = 0; i < A_IT; ++i) a_ptr[i] += a_step[i];
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) a_ptr[i] += BK2;
+            for (int i = 0; i < A_IT; ++i) a_ptr[i] += a_step[i];
         }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) b_ptr[i] += BK2;
+        for (int i = 0; i < B_IT; ++i) b_ptr[i] += b_step[i];
     };
 
     // position the loaders at the split's first slab
@@ -520,10 +545,10 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GemmParams p) {
         conv_seek(kt_begin * BK2);
     } else {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) a_ptr[i] += (long long)kt_begin * BK2;
+        for (int i = 0; i < A_IT; ++i) a_ptr[i] += (long long)kt_begin * a_step[i];
     }
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) b_ptr[i] += (long long)kt_begin * BK2;
+    for (int i = 0; i < B_IT; ++i) b_ptr[i] += (long long)kt_begin * b_step[i];
 
     // ---- fragment read offsets (halfs, within a stage)
     const int fr = lane & 15, fq = lane >> 4;
@@ -551,29 +576,300 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GemmParams p) {
 
     constexpr int LPT_HI = A_IT + B_IT;          // loads per slab, waves 0-1
     constexpr int LPT_LO = A_IT + B_FULL;        // waves 2-3
-    int st = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        // slab kt has landed for this wave once all but the youngest PF-1 slabs' loads are done
+    // Register double-buffered fragments: the ds_reads of slab t+1 are issued BEFORE the MFMAs of slab t, so their
+    // latency hides under 20 (16) MFMAs instead of stalling every slab.  Per step:
+    //   [slab t+1 landed: counted vmcnt] [barrier] [refill the stage slab t used] [read frags(t+1)] [MFMA frags(t)]
+    //   [lgkmcnt(0): frags(t+1) are in registers, so the NEXT barrier also proves nobody still reads slab t+1's stage... ]
+    half8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto wait_landed = [&]() {
         if (B_TAIL && tail_wave) wait_vmcnt<LPT_HI * (PF - 1)>();
         else wait_vmcnt<LPT_LO * (PF - 1)>();
-        __builtin_amdgcn_s_barrier();            // ... for every wave; and every wave has finished reading slab kt-1
-        issue(kt + PF, (st + PF) & (NST - 1));   // refill the stage slab kt-1 occupied
-        const half_t* S = smem + st * STAGE;
-        half8 bf[TN];
+    };
+    auto read_frags = [&](int stg, half8 (&fa)[TM], half8 (&fb)[TN]) {
+        const half_t* S = smem + stg * STAGE;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = as_half8(ld16(S + b_off[j]));
+        for (int j = 0; j < TN; ++j) fb[j] = as_half8(ld16(S + b_off[j]));
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const half8 af = as_half8(ld16(S + a_off[i]));
+        for (int i = 0; i < TM; ++i) fa[i] = as_half8(ld16(S + a_off[i]));
+    };
+    auto mma = [&](const half8 (&fa)[TM], const half8 (&fb)[TN]) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af, acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+    // one pipeline step: consume `cur` (slab kt, already in registers), fetch slab kt+1 into `nxt`
+    auto step = [&](int kt, int st, const half8 (&cfa)[TM], const half8 (&cfb)[TN], half8 (&nfa)[TM], half8 (&nfb)[TN]) {
+        wait_landed();                               // slab kt+1 landed (this wave's share)
+        __builtin_amdgcn_s_barrier();                // ... everyone's share; and all reads of slab kt's stage have completed
+        issue(kt + PF + 1, st);                      // refill the stage slab kt occupied
+        read_frags((st + 1) & (NST - 1), nfa, nfb);  // slab kt+1 -> registers (latency hidden by the MFMAs below)
+        __builtin_amdgcn_sched_barrier(0);           // keep the reads AHEAD of the MFMAs (hipcc otherwise sinks them below
+        mma(cfa, cfb);                               //  the MFMAs and reuses the fragment registers: latency exposed)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    int st = 0;
+    {   // slab kt_begin -> registers
+        if (B_TAIL && tail_wave) wait_vmcnt<LPT_HI * (PF - 1)>();
+        else wait_vmcnt<LPT_LO * (PF - 1)>();
+        __builtin_amdgcn_s_barrier();
+        issue(kt_begin + PF, PF);                    // 4th stage: now PF+... slabs are in flight again
+        read_frags(0, fa0, fb0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    int kt = kt_begin;
+    for (; kt + 1 < kt_end; kt += 2) {
+        step(kt, st, fa0, fb0, fa1, fb1);
+        st = (st + 1) & (NST - 1);
+        step(kt + 1, st, fa1, fb1, fa0, fb0);
         st = (st + 1) & (NST - 1);
     }
+    if (kt < kt_end) mma(fa0, fb0);                  // odd slab count: the last slab is already in registers
     wait_vmcnt<0>();                             // drain the look-ahead (zero-page) loads before the ring is reused
     __builtin_amdgcn_s_barrier();
 
     // ---- epilogue (identical to v1)
+    if (splitk > 1) {
+        float* part = p.partial + (long long)ks * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm0 + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn0 + j * 16 + fq * 4;
+                if (m < p.M && n < p.N) {
+                    f32x4 v = acc[i][j];
+                    v *= p.alpha;
+                    *reinterpret_cast<f32x4*>(part + (long long)m * p.N + n) = v;
+                }
+            }
+        }
+        return;
+    }
+    half_t* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm0 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn0 + j * 16 + fq * 4;
+            half4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] * p.alpha);
+            *reinterpret_cast<half4*>(Cs + ml * CLD + nl) = h;
+        }
+    }
+    __syncthreads();
+    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid);
+}
+
+// =====================================================================================================================
+// v3: the same LDS-DMA ring with 64-wide K slabs and ONE workgroup per CU (4 stages x (BM+BN) x 128 B = up to 147 KB).
+// One barrier per 2 k-steps (40 MFMAs per wave), fragments double-buffered at k-step granularity.  128-byte LDS rows use
+// the chunk ^ (row & 7) swizzle (conflict-free for the 16x16x32 fragment reads, as in v1).  Chosen for long-K problems.
+// =====================================================================================================================
+template <int BM, int BN, bool CONV, int NST>
+__global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmParams p) {
+    constexpr int BK3 = 64, PF = NST - 1;
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_CH = BM * 8, B_CH = BN * 8;
+    constexpr int A_IT = A_CH / NT;                             // 4 (BM=128) or 2 (BM=64)
+    constexpr int B_IT = B_CH / NT;                             // 5 (BN=160) or 4 (BN=128): exact, no tail
+    static_assert(B_CH % NT == 0 && A_CH % NT == 0, "whole instructions per wave");
+    constexpr int STAGE = (BM + BN) * BK3;
+    constexpr int CLD = BN + 8;
+    static_assert(BM * CLD <= NST * STAGE, "epilogue tile must fit in the ring");
+    __shared__ __attribute__((aligned(16))) half_t smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
+    const int z = blockIdx.z;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles = tiles_m * tiles_n;
+    const int splitk = p.splitk > 1 ? p.splitk : 1;
+    int bid = xcd_remap(blockIdx.x, tiles * splitk);
+    const int ks = bid / tiles;
+    bid -= ks * tiles;
+    const int tn_i = p.m_fastest ? bid / tiles_m : bid % tiles_n;
+    const int tm_i = p.m_fastest ? bid % tiles_m : bid / tiles_n;
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int KT = (p.K + BK3 - 1) / BK3;
+    const int kt_begin = (int)((long long)ks * KT / splitk), kt_end = (int)((long long)(ks + 1) * KT / splitk);
+
+    const half_t* Ab = p.A + (long long)z * p.sA;
+    const half_t* Wb = p.W + (long long)z * p.sW;
+    const half_t* zp = reinterpret_cast<const half_t*>(g_zero_page);
+    const int Cin = p.C1 + p.C2;
+
+    int a_lc[A_IT];
+    bool a_ok[A_IT];
+    int a_img[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+    const half_t* a_ptr[A_IT];
+    bool a_val[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int q = tid + i * NT;
+        const int row = q >> 3;
+        a_lc[i] = (q & 7) ^ (row & 7);
+        const int m = m0 + row;
+        a_ok[i] = m < p.M;
+        a_img[i] = a_iy0[i] = a_ix0[i] = 0;
+        a_ptr[i] = zp;
+        a_val[i] = false;
+        if (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int mm = a_ok[i] ? m : 0;
+            const int img = mm / hw, rem = mm - img * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_img[i] = img;
+            a_iy0[i] = oy * p.stride - (p.ksize >> 1);
+            a_ix0[i] = ox * p.stride - (p.ksize >> 1);
+        } else {
+            a_ptr[i] = Ab + (long long)(a_ok[i] ? m : 0) * p.lda + a_lc[i] * 8;
+        }
+    }
+    int seg_left = 0;
+    auto conv_seek = [&](int k0) {
+        const int tap = k0 / Cin;
+        const int c0 = k0 - tap * Cin;
+        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+        const bool second = c0 >= p.C1;
+        const half_t* src = second ? p.A2 : Ab;
+        const int Cs = second ? p.C2 : p.C1;
+        const int cl = second ? c0 - p.C1 : c0;
+        seg_left = ((second ? Cin : p.C1) - c0) / BK3;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv && tap < p.ksize * p.ksize;
+            int sy = iy, sx = ix;
+            if (p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws) {
+                sy = iy >> 1;
+                sx = ix >> 1;
+            } else if (p.Hv != p.Hs || p.Wv != p.Ws) {
+                sy = (int)((long long)iy * p.Hs / p.Hv);
+                sx = (int)((long long)ix * p.Ws / p.Wv);
+            }
+            a_val[i] = ok;
+            a_ptr[i] = ok ? src + (((long long)a_img[i] * p.Hs + sy) * p.Ws + sx) * Cs + cl + a_lc[i] * 8 : zp;
+        }
+    };
+    const half_t* b_ptr[B_IT];
+    bool b_ok[B_IT];
+    int b_lc[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int q = tid + i * NT;
+        const int row = q >> 3;
+        b_lc[i] = (q & 7) ^ (row & 7);
+        b_ok[i] = n0 + row < p.n_valid;
+        b_ptr[i] = Wb + (long long)(b_ok[i] ? n0 + row : 0) * p.ldw + b_lc[i] * 8;
+    }
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    auto issue = [&](int kt, int st) {
+        const unsigned As = smem_base + (unsigned)(st * STAGE) * 2u;
+        const unsigned Bs = As + (unsigned)(BM * BK3) * 2u;
+        const bool live = kt < kt_end;
+        const int k0 = kt * BK3;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const half_t* src;
+            if (CONV) src = (live && a_val[i]) ? a_ptr[i] : zp;
+            else src = (live && a_ok[i] && k0 + a_lc[i] * 8 < p.K) ? a_ptr[i] : zp;
+            glds16(src, As + (unsigned)(i * NT + wid * 64) * 16u);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const half_t* src = (live && b_ok[i] && k0 + b_lc[i] * 8 < p.K) ? b_ptr[i] : zp;
+            glds16(src, Bs + (unsigned)(i * NT + wid * 64) * 16u);
+        }
+        if (CONV) {
+            if (--seg_left <= 0) {
+                conv_seek(k0 + BK3);
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) a_ptr[i] += a_val[i] ? BK3 : 0;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) a_ptr[i] += BK3;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) b_ptr[i] += BK3;
+    };
+    if (CONV) {
+        conv_seek(kt_begin * BK3);
+    } else {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) a_ptr[i] += (long long)kt_begin * BK3;
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) b_ptr[i] += (long long)kt_begin * BK3;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int a_row[TM], b_row[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_row[i] = wm0 + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_row[j] = wn0 + j * 16 + fr;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int t = 0; t < PF; ++t) issue(kt_begin + t, t);
+    constexpr int LPT = A_IT + B_IT;
+
+    half8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto read_frags = [&](int stg, int kk, half8 (&fa)[TM], half8 (&fb)[TN]) {
+        const half_t* S = smem + stg * STAGE;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = as_half8(ld16(S + BM * BK3 + b_row[j] * BK3 + (((kk * 4 + fq) ^ (b_row[j] & 7)) << 3)));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = as_half8(ld16(S + a_row[i] * BK3 + (((kk * 4 + fq) ^ (a_row[i] & 7)) << 3)));
+    };
+    auto mma = [&](const half8 (&fa)[TM], const half8 (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+
+    wait_vmcnt<LPT * (PF - 1)>();                    // slab kt_begin landed
+    __builtin_amdgcn_s_barrier();
+    issue(kt_begin + PF, PF);
+    read_frags(0, 0, fa0, fb0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int st = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        // k-step 0 of slab kt is in set 0: fetch k-step 1 of the same slab under its MFMAs
+        read_frags(st, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // slab kt+1: landed for this wave, then for all (and nobody reads slab kt's stage any more)
+        wait_vmcnt<LPT * (PF - 1)>();
+        __builtin_amdgcn_s_barrier();
+        issue(kt + PF + 1, st);
+        const int sn = (st + 1) & (NST - 1);
+        read_frags(sn, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        st = sn;
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
     if (splitk > 1) {
         float* part = p.partial + (long long)ks * p.M * p.N;
 #pragma unroll
@@ -658,6 +954,15 @@ bool use_v1() {
     static const bool v = getenv("LD_GEMM_V1") != nullptr;
     return v;
 }
+int v3_min_k() {   // K from which the 64-wide-slab kernel (v3) is used instead of v2; LD_GEMM_V3_MINK overrides, 0 = never.
+    // measured (profiles/r01_c): v3 with a 2-stage ring wins or ties v2 on every shape of the UNet, so the default is "always"
+    static const int v = getenv("LD_GEMM_V3_MINK") ? atoi(getenv("LD_GEMM_V3_MINK")) : 1;
+    return v;
+}
+int v3_stages() {  // 2: two-stage ring, 2 blocks/CU;  4: four-stage ring, 1 block/CU
+    static const int v = getenv("LD_GEMM_V3_NST") ? atoi(getenv("LD_GEMM_V3_NST")) : 2;
+    return v;
+}
 
 template <int BM, int BN>
 void launch_cfg(const GemmParams& p, hipStream_t s) {
@@ -669,6 +974,18 @@ void launch_cfg(const GemmParams& p, hipStream_t s) {
             hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, block, 0, s, p);
         else
             hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, block, 0, s, p);
+    } else if (v3_min_k() > 0 && p.K / sk >= v3_min_k()) {
+        if (v3_stages() == 4) {
+            if (p.conv)
+                hipLaunchKernelGGL((gemm3_kernel<BM, BN, true, 4>), grid, block, 0, s, p);
+            else
+                hipLaunchKernelGGL((gemm3_kernel<BM, BN, false, 4>), grid, block, 0, s, p);
+        } else {
+            if (p.conv)
+                hipLaunchKernelGGL((gemm3_kernel<BM, BN, true, 2>), grid, block, 0, s, p);
+            else
+                hipLaunchKernelGGL((gemm3_kernel<BM, BN, false, 2>), grid, block, 0, s, p);
+        }
     } else {
         if (p.conv)
             hipLaunchKernelGGL((gemm2_kernel<BM, BN, true>), grid, block, 0, s, p);
@@ -697,6 +1014,10 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (p.R != nullptr && (p.ldr & 7)) return LD_ERR_SHAPE;
 
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
+    static const int env_bm = getenv("LD_GEMM_BM") ? atoi(getenv("LD_GEMM_BM")) : 0;   // experiments only
+    static const int env_bn = getenv("LD_GEMM_BN") ? atoi(getenv("LD_GEMM_BN")) : 0;
+    if (env_bm && p.bm == 0) p.bm = env_bm;
+    if (env_bn && p.bn == 0 && p.act != 2) p.bn = env_bn;
     int bn = p.bn ? p.bn : gemm_pick_bn(p.N);
     if (bn != 128 && bn != 160) return LD_ERR_ARG;
     if (p.act == 2 && (p.N % bn)) return LD_ERR_SHAPE;
