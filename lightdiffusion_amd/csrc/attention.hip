@@ -12,21 +12,22 @@
 //  * K/V tiles (64 keys) are prefetched global->registers under the MFMA phase of the previous tile (T14).
 //  * O rescale is skipped (wave-uniform branch) whenever no running max moved — exact, not thresholded.
 // Head dims: d % 8 == 0, d <= 160 (SD1.5: 40 / 80 / 160).  Template DK = ceil(d/16) k-steps of QK^T.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace {
 
 constexpr int AT_THREADS = 256;
-constexpr int KT_KEYS = 64;   // keys per LDS tile
 
-template <int DK>
+template <int DK, int KT_KEYS, int SMX = 1>   // KT_KEYS: keys per LDS tile (64 or 128); SMX: softmax code variant (A/B)
 __global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams p) {
     constexpr int DV = (DK + 1) / 2;            // 32-row tiles of O^T
     constexpr bool ONES = (DK & 1) != 0;        // d <= 16*DK < 32*DV: a spare V^T row exists -> row-sum of P by MFMA
     constexpr int KLD = 16 * DK + 8;            // K tile row stride (halfs)
     constexpr int VLD = KT_KEYS + 8;            // V^T tile row stride (halfs)
     constexpr int KCH = KT_KEYS * 2 * DK;       // 16-byte chunks in a (padded-d) K tile
-    constexpr int VCH = 32 * DV * 8;            // chunks in a V^T tile
+    constexpr int VCH = 32 * DV * (KT_KEYS / 8); // chunks in a V^T tile
     constexpr int KIT = (KCH + AT_THREADS - 1) / AT_THREADS;
     constexpr int VIT = (VCH + AT_THREADS - 1) / AT_THREADS;
     __shared__ __attribute__((aligned(16))) half_t Ks[KT_KEYS * KLD];
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
             const int q = tid + i * AT_THREADS;
-            const int row = q >> 3, cc = q & 7;
+            const int row = q / (KT_KEYS / 8), cc = q - row * (KT_KEYS / 8);
             const bool ok = q < VCH && row < d && key0 + cc * 8 < p.Lk;
             // spare row 32*DV-1 := 1.0 (fp16 0x3C00): O^T row 32*DV-1 then accumulates sum_k P[k], the softmax
             // denominator, on the matrix core instead of 16 VALU adds per tile
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams
 #pragma unroll
         for (int i = 0; i < VIT; ++i) {
             const int q = tid + i * AT_THREADS;
-            const int row = q >> 3, cc = q & 7;
+            const int row = q / (KT_KEYS / 8), cc = q - row * (KT_KEYS / 8);
             if (q < VCH) st16(Vs + row * VLD + cc * 8, rv[i]);
         }
     };
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams
         __syncthreads();
         if (t + 1 < ntiles) prefetch(key0 + KT_KEYS);
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < KT_KEYS / 32; ++sub) {
             if (key0 + sub * 32 >= p.Lk) break;   // wave-uniform: nothing valid in this half tile
             f32x16 s;
 #pragma unroll
@@ -133,19 +134,38 @@ __global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams
                     if (key0 + sub * 32 + key >= p.Lk) s[e] = -INFINITY;
                 }
             }
-            float mx = s[0];
+            float mx;
+            if (SMX == 1) {
+                // 16 -> 1 as a tree of 3-input maxima (v_max3_f32): 8 instructions instead of 15
+                mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
-            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
+                for (int e = 3; e + 1 < 16; e += 2) mx = fmaxf(fmaxf(mx, s[e]), s[e + 1]);
+                mx = fmaxf(mx, s[15]);
+            } else {
+                mx = s[0];
+#pragma unroll
+                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
             const float mc = m_new * c2;
             float psum = 0.f;
             half8 pf[2];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pe = __builtin_amdgcn_exp2f(s[e] * c2 - mc);   // raw v_exp_f32: argument <= 0, flush of denormals is fine
-                if (!ONES) psum += pe;
-                pf[e >> 3][e & 7] = (half_t)pe;
+            for (int e = 0; e < 16; e += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[e] * c2 - mc);       // raw v_exp_f32: argument <= 0
+                const float p1 = __builtin_amdgcn_exp2f(s[e + 1] * c2 - mc);
+                if (!ONES) psum += p0 + p1;
+                // one v_cvt_pkrtz_f16_f32 per pair (instead of 2 cvt + 1 pack).  Round-toward-zero biases P by < 2^-10
+                // relative; numerator and (MFMA row-sum) denominator are built from the same rounded P, so it cancels.
+                if (SMX == 1) {
+                    const half2v h2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+                    pf[e >> 3][e & 7] = h2[0];
+                    pf[e >> 3][(e & 7) + 1] = h2[1];
+                } else {
+                    pf[e >> 3][e & 7] = (half_t)p0;
+                    pf[e >> 3][(e & 7) + 1] = (half_t)p1;
+                }
             }
             if (__any(m_new > m_run)) {
                 const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
@@ -194,8 +214,15 @@ __global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams
 
 template <int DK>
 void launch_attn(const AttnParams& p, hipStream_t s) {
+    static const int env_kt = getenv("LD_ATTN_KT") ? atoi(getenv("LD_ATTN_KT")) : 64;   // A/B knob; 64 measured best (profiles/r01_c)
     const int nblk = ((p.Lq + 127) / 128) * p.H * p.B;
-    hipLaunchKernelGGL((flash_attn_kernel<DK>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
+    static const int env_smx = getenv("LD_ATTN_SMX") ? atoi(getenv("LD_ATTN_SMX")) : 1;
+    if (DK <= 5 && env_kt == 128)
+        hipLaunchKernelGGL((flash_attn_kernel<DK, (DK <= 5 ? 128 : 64)>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
+    else if (env_smx == 0)
+        hipLaunchKernelGGL((flash_attn_kernel<DK, 64, 0>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
+    else
+        hipLaunchKernelGGL((flash_attn_kernel<DK, 64, 1>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
 }
 
 }  // namespace
