@@ -83,6 +83,7 @@ typedef struct {
     int z_channels, ch, num_levels;
     int ch_mult[8];
     int num_res_blocks, out_ch;
+    int with_encoder;   /* != 0: also hold encoder.* and quant_conv.* (VAE.encode path) */
 } ld_vae_config;
 
 typedef struct ld_vae ld_vae;
@@ -96,6 +97,9 @@ int ld_vae_reserve(ld_vae* v, int max_b, int max_h, int max_w);   /* latent size
 size_t ld_vae_workspace_bytes(const ld_vae* v);
 /* z: [b][z_channels][h][w] fp32 (already divided by 0.18215); out: [b][8h][8w][3] fp32 in [0,1] */
 int ld_vae_decode(ld_vae* v, const float* z, float* out, int b, int h, int w, void* stream);
+/* VAE.encode's device part (LD.py:6383-6410): pixels fp32 NCHW [b][3][8h][8w] in [-1,1] -> moments fp32 NCHW [b][2z][h][w]
+ * (mean | logvar, before DiagonalGaussianRegularizer's host-RNG sample, LD.py:3446-3458); (h, w) = latent size */
+int ld_vae_encode(ld_vae* v, const float* pixels_nchw, float* moments, int b, int h, int w, void* stream);
 int ld_vae_last_launches(const ld_vae* v);
 double ld_vae_last_flops(const ld_vae* v);
 

@@ -24,7 +24,7 @@ class UNetConfig(C.Structure):
 
 class VAEConfig(C.Structure):
     _fields_ = [("z_channels", C.c_int), ("ch", C.c_int), ("num_levels", C.c_int), ("ch_mult", C.c_int * 8),
-                ("num_res_blocks", C.c_int), ("out_ch", C.c_int)]
+                ("num_res_blocks", C.c_int), ("out_ch", C.c_int), ("with_encoder", C.c_int)]
 
 
 class LDError(RuntimeError):
@@ -62,6 +62,7 @@ SIGNATURES = {
     "ld_vae_reserve": (_I, [_P, _I, _I, _I]),
     "ld_vae_workspace_bytes": (_Z, [_P]),
     "ld_vae_decode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ld_vae_encode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ld_vae_last_launches": (_I, [_P]),
     "ld_vae_last_flops": (C.c_double, [_P]),
     "ld_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _Z, _P]),

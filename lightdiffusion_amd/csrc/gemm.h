@@ -11,6 +11,7 @@ struct GemmParams {
     int lda = 0;
     int conv = 0;                // 0 plain, 1 implicit im2col conv (ksize x ksize, pad ksize/2)
     int ksize = 3;               // 1 or 3
+    int pad = -1;                // top/left zero padding; -1 = ksize/2 (bottom/right padding is implied by Ho, Wo)
     int Hs = 0, Ws = 0;          // source spatial size
     int Hv = 0, Wv = 0;          // size the conv sees (after nearest resize; == Hs,Ws without upsample)
     int Ho = 0, Wo = 0, stride = 1;

@@ -183,8 +183,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
             const int img = mm / hw, rem = mm - img * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             a_base[i] = img;
-            a_iy0[i] = oy * p.stride - (p.ksize >> 1);
-            a_ix0[i] = ox * p.stride - (p.ksize >> 1);
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
         } else {
             a_base[i] = (long long)m * p.lda;
             a_iy0[i] = a_ix0[i] = 0;
@@ -426,8 +426,8 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GemmParams p) {
             const int img = mm / hw, rem = mm - img * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             a_img[i] = img;
-            a_iy0[i] = oy * p.stride - (p.ksize >> 1);
-            a_ix0[i] = ox * p.stride - (p.ksize >> 1);
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
         } else {
             a_ptr[i] = Ab + (long long)(a_ok[i] ? m : 0) * p.lda + a_lc[i] * 8;
         }
@@ -726,8 +726,8 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
             const int img = mm / hw, rem = mm - img * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             a_img[i] = img;
-            a_iy0[i] = oy * p.stride - (p.ksize >> 1);
-            a_ix0[i] = ox * p.stride - (p.ksize >> 1);
+            a_iy0[i] = oy * p.stride - p.pad;
+            a_ix0[i] = ox * p.stride - p.pad;
         } else {
             a_ptr[i] = Ab + (long long)(a_ok[i] ? m : 0) * p.lda + a_lc[i] * 8;
         }
@@ -996,13 +996,23 @@ void launch_cfg(const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
+// tuning hook (tools/gemm_sweep.py): force tile height / split-K for every following launch; 0 = automatic
+static int g_force_bm = 0, g_force_sk = 0;
+extern "C" void ld_debug_gemm_override(int bm, int splitk) {
+    g_force_bm = bm;
+    g_force_sk = splitk;
+}
+
 int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     GemmParams p = pin;
+    if (g_force_bm) p.bm = g_force_bm;
+    if (g_force_sk) p.splitk = g_force_sk;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.A == nullptr || p.W == nullptr || p.C == nullptr) return LD_ERR_ARG;
     if ((p.N & 7) || (p.K & 7) || (p.ldw & 7) || (p.ldc & 7)) return LD_ERR_SHAPE;
     if (p.conv) {
         const int Cin = p.C1 + p.C2;
         if (p.ksize != 1 && p.ksize != 3) return LD_ERR_ARG;
+        if (p.pad < 0) p.pad = p.ksize >> 1;
         if (Cin <= 0 || (p.C1 % 64) || (p.C2 % 64) || p.K != p.ksize * p.ksize * Cin) return LD_ERR_SHAPE;
         if (p.C2 > 0 && p.A2 == nullptr) return LD_ERR_ARG;
         if (p.M % (p.Ho * p.Wo)) return LD_ERR_SHAPE;
@@ -1022,20 +1032,36 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (bn != 128 && bn != 160) return LD_ERR_ARG;
     if (p.act == 2 && (p.N % bn)) return LD_ERR_SHAPE;
     const int tiles_n = (p.N + bn - 1) / bn;
-    int bm = p.bm;
-    if (bm == 0) bm = (((p.M + 127) / 128) * tiles_n * p.batch >= 256) ? 128 : 64;
+    const int KT = (p.K + BK - 1) / BK;          // 64-wide K slabs
+    // Tile height and split-K, fitted to a per-shape sweep of every contraction of the SD1.5 UNet at UNet batch 2 and 16
+    // (tools/gemm_sweep.py, profiles/README.md): bigger tiles win whenever they fill the chip; a split only pays when each
+    // slice keeps >= ~768 of K (its second pass is a ~6 us launch plus fp32 slab traffic); short-K problems prefer
+    // 64-row tiles and no split; long-K problems prefer 128-row tiles and a split up to ~2 blocks per CU.
+    const int tiles128 = ((p.M + 127) / 128) * tiles_n * p.batch;
+    const bool can_split = p.batch == 1 && p.partial != nullptr;
+    const int sk_cap = p.K / 768 < 1 ? 1 : (p.K / 768 > 16 ? 16 : p.K / 768);
+    int bm = p.bm, sk = p.splitk;
+    static const bool old_heur = getenv("LD_GEMM_HEUR_OLD") != nullptr;   // A/B knob: the pre-sweep rule
+    if (bm == 0) {
+        if (old_heur) bm = tiles128 >= 256 ? 128 : 64;
+        else if (tiles128 >= 512) bm = 128;
+        else if (p.K >= 4096 && tiles128 >= 32 && can_split) bm = 128;
+        else bm = 64;
+    }
     if (bm != 64 && bm != 128) return LD_ERR_ARG;
     const int tiles = ((p.M + bm - 1) / bm) * tiles_n;
-    const int KT = (p.K + BK - 1) / BK;          // 64-wide units (v2 slabs are 32 wide: twice as many, same split points)
-
-    int sk = p.splitk;
-    if (sk == 0) {   // auto: fill ~2 blocks per CU when the tile grid alone cannot
+    if (sk == 0) {
         sk = 1;
-        if (p.batch == 1 && p.partial != nullptr && tiles < 384 && KT >= 8) {
+        if (old_heur) {
+            if (can_split && tiles < 384 && KT >= 8) {
+                sk = (512 + tiles - 1) / tiles;
+                if (sk > KT / 4) sk = KT / 4;
+                if (sk > 32) sk = 32;
+                if (sk < 1) sk = 1;
+            }
+        } else if (can_split && tiles * p.batch < 512) {
             sk = (512 + tiles - 1) / tiles;
-            if (sk > KT / 4) sk = KT / 4;
-            if (sk > 32) sk = 32;
-            if (sk < 1) sk = 1;
+            if (sk > sk_cap) sk = sk_cap;
         }
     }
     if (sk > 1) {

@@ -59,6 +59,8 @@ struct SmallConvOutArgs {       // 3x3 pad-1 conv to <= 4 output channels from a
 };
 int small_conv_out_launch(const SmallConvOutArgs& a, hipStream_t stream);
 
+int small_pointwise_launch(const half_t* x, const half_t* w, const half_t* b, float* out, int N, int HW, int C, hipStream_t stream);
+
 // timestep lookup + sinusoidal embedding: sigma[N] -> t = argmin |log sigma - log_sigmas| -> [N][dim] fp16 (cos | sin)
 int timestep_embed_launch(const float* sigma, const float* log_sigmas, int n_sig, int N, int dim, half_t* out, float* t_out,
                           hipStream_t stream);

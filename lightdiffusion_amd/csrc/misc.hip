@@ -128,6 +128,23 @@ __global__ __launch_bounds__(256) void small_conv_out_kernel(const SmallConvOutA
     }
 }
 
+// ------------------------------------------------------------------------------------------------ tiny 1x1 conv
+// out[n][o][pix] (fp32 NCHW) = bias[o] + sum_c w[o][c] * x[n][pix][c] (fp16 NHWC), C <= 8: the VAE's quant_conv (LD.py:3468, 3478)
+__global__ void small_pointwise_kernel(const half_t* x, const half_t* w, const half_t* b, float* out, int N, int HW, int C) {
+    const long long total = (long long)N * HW;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(q / HW);
+        const long long pix = q - (long long)n * HW;
+        float v[8];
+        unpack8(ld16(x + q * 8), v);           // rows are padded to 8 channels by the caller (C == 8 here)
+        for (int o = 0; o < C; ++o) {
+            float s = (float)b[o];
+            for (int c = 0; c < C; ++c) s += (float)w[o * C + c] * (float)(half_t)v[c];
+            out[((long long)n * C + o) * HW + pix] = (float)(half_t)s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ timestep embedding
 // ModelSamplingDiscrete.timestep (LD.py:1336-1339) + timestep_embedding (LD.py:803-812).  One block per sample.
 __global__ __launch_bounds__(256) void timestep_embed_kernel(const float* sigma, const float* log_sigmas, int n_sig, int dim,
@@ -260,6 +277,13 @@ int small_conv_out_launch(const SmallConvOutArgs& a, hipStream_t stream) {
     if (a.mode == 0 && (a.x_in == nullptr || a.sigma == nullptr)) return LD_ERR_ARG;
     const long long npix = (long long)a.N * a.H * a.W;
     hipLaunchKernelGGL(small_conv_out_kernel, dim3(grid_for(npix, 4, 8192)), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int small_pointwise_launch(const half_t* x, const half_t* w, const half_t* b, float* out, int N, int HW, int C, hipStream_t stream) {
+    if (x == nullptr || w == nullptr || b == nullptr || out == nullptr) return LD_ERR_ARG;
+    if (C != 8) return LD_ERR_SHAPE;
+    hipLaunchKernelGGL(small_pointwise_kernel, dim3(grid_for((long long)N * HW, 256)), dim3(256), 0, stream, x, w, b, out, N, HW, C);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
 

@@ -13,6 +13,10 @@ struct VResW {
     int cin, cout;
     int n1_g, n1_b, c1_w, c1_b, n2_g, n2_b, c2_w, c2_b, nin_w = -1, nin_b = -1;
 };
+struct VAttnW {
+    int c = 0;
+    int n_g, n_b, q_w, q_b, k_w, k_b, v_w, v_b, o_w, o_b;
+};
 }  // namespace
 
 struct ld_vae {
@@ -20,8 +24,14 @@ struct ld_vae {
     ParamTable pt;
     int pq_w, pq_b, cin_w, cin_b;
     VResW mid1, mid2;
-    int an_g, an_b, aq_w, aq_b, ak_w, ak_b, av_w, av_b, ao_w, ao_b;
+    VAttnW mid_attn;
     std::vector<std::vector<VResW>> up;   // [level][block]
+    // encoder (Encoder, LD.py:3649-3758 + quant_conv 3468), present when cfg.with_encoder
+    int e_cin_w = -1, e_cin_b = -1, e_no_g = -1, e_no_b = -1, e_co_w = -1, e_co_b = -1, e_q_w = -1, e_q_b = -1;
+    std::vector<std::vector<VResW>> down;
+    std::vector<int> dwn_w, dwn_b;
+    VResW e_mid1, e_mid2;
+    VAttnW e_attn;
     std::vector<int> ups_w, ups_b;        // [level] (-1 at level 0)
     int no_g, no_b, co_w, co_b;
     int block_in0 = 0;
@@ -57,6 +67,23 @@ VResW add_vres(ld_vae* v, const std::string& p, int cin, int cout) {
     return r;
 }
 
+VAttnW add_vattn(ld_vae* v, const std::string& p, int c) {
+    ParamTable& t = v->pt;
+    VAttnW a;
+    a.c = c;
+    a.n_g = t.add(p + ".norm.weight", PK_VEC, {c});
+    a.n_b = t.add(p + ".norm.bias", PK_VEC, {c});
+    a.q_w = t.add(p + ".q.weight", PK_MAT, {c, c, 1, 1});
+    a.k_w = t.add(p + ".k.weight", PK_MAT, {c, c, 1, 1}, 16);   // [q;k] as one [2C][C] projection
+    a.q_b = t.add(p + ".q.bias", PK_VEC, {c});
+    a.k_b = t.add(p + ".k.bias", PK_VEC, {c}, 16);
+    a.v_w = t.add(p + ".v.weight", PK_MAT, {c, c, 1, 1});
+    a.v_b = t.add(p + ".v.bias", PK_VEC, {c});
+    a.o_w = t.add(p + ".proj_out.weight", PK_MAT, {c, c, 1, 1});
+    a.o_b = t.add(p + ".proj_out.bias", PK_VEC, {c});
+    return a;
+}
+
 int build(ld_vae* v) {
     const ld_vae_config& c = v->cfg;
     if (c.num_levels < 1 || c.num_levels > 8 || c.z_channels < 1 || c.z_channels > 4 || c.out_ch < 1 || c.out_ch > 4) return LD_ERR_ARG;
@@ -70,16 +97,7 @@ int build(ld_vae* v) {
     v->cin_w = t.add("decoder.conv_in.weight", PK_CONV3, {bi, z, 3, 3});
     v->cin_b = t.add("decoder.conv_in.bias", PK_VEC, {bi});
     v->mid1 = add_vres(v, "decoder.mid.block_1", bi, bi);
-    v->an_g = t.add("decoder.mid.attn_1.norm.weight", PK_VEC, {bi});
-    v->an_b = t.add("decoder.mid.attn_1.norm.bias", PK_VEC, {bi});
-    v->aq_w = t.add("decoder.mid.attn_1.q.weight", PK_MAT, {bi, bi, 1, 1});
-    v->ak_w = t.add("decoder.mid.attn_1.k.weight", PK_MAT, {bi, bi, 1, 1}, 16);   // [q;k] as one [2C][C] projection
-    v->aq_b = t.add("decoder.mid.attn_1.q.bias", PK_VEC, {bi});
-    v->ak_b = t.add("decoder.mid.attn_1.k.bias", PK_VEC, {bi}, 16);
-    v->av_w = t.add("decoder.mid.attn_1.v.weight", PK_MAT, {bi, bi, 1, 1});
-    v->av_b = t.add("decoder.mid.attn_1.v.bias", PK_VEC, {bi});
-    v->ao_w = t.add("decoder.mid.attn_1.proj_out.weight", PK_MAT, {bi, bi, 1, 1});
-    v->ao_b = t.add("decoder.mid.attn_1.proj_out.bias", PK_VEC, {bi});
+    v->mid_attn = add_vattn(v, "decoder.mid.attn_1", bi);
     v->mid2 = add_vres(v, "decoder.mid.block_2", bi, bi);
     v->up.assign(c.num_levels, {});
     v->ups_w.assign(c.num_levels, -1);
@@ -103,6 +121,37 @@ int build(ld_vae* v) {
     v->no_b = t.add("decoder.norm_out.bias", PK_VEC, {bi});
     v->co_w = t.add("decoder.conv_out.weight", PK_CONV3, {c.out_ch, bi, 3, 3});
     v->co_b = t.add("decoder.conv_out.bias", PK_VEC, {c.out_ch});
+    if (c.with_encoder) {
+        if (2 * z != 8 || c.out_ch > 4) return LD_ERR_SHAPE;          // moments are 8 channels (double_z of z_channels 4)
+        v->e_cin_w = t.add("encoder.conv_in.weight", PK_CONV3, {c.ch, c.out_ch, 3, 3});
+        v->e_cin_b = t.add("encoder.conv_in.bias", PK_VEC, {c.ch});
+        v->down.assign(c.num_levels, {});
+        v->dwn_w.assign(c.num_levels, -1);
+        v->dwn_b.assign(c.num_levels, -1);
+        int ei = c.ch;
+        for (int lvl = 0; lvl < c.num_levels; ++lvl) {
+            const int eo = c.ch * c.ch_mult[lvl];
+            for (int b = 0; b < c.num_res_blocks; ++b) {
+                snprintf(buf, sizeof buf, "encoder.down.%d.block.%d", lvl, b);
+                v->down[lvl].push_back(add_vres(v, buf, ei, eo));
+                ei = eo;
+            }
+            if (lvl != c.num_levels - 1) {
+                snprintf(buf, sizeof buf, "encoder.down.%d.downsample.conv", lvl);
+                v->dwn_w[lvl] = t.add(std::string(buf) + ".weight", PK_CONV3, {ei, ei, 3, 3});
+                v->dwn_b[lvl] = t.add(std::string(buf) + ".bias", PK_VEC, {ei});
+            }
+        }
+        v->e_mid1 = add_vres(v, "encoder.mid.block_1", ei, ei);
+        v->e_attn = add_vattn(v, "encoder.mid.attn_1", ei);
+        v->e_mid2 = add_vres(v, "encoder.mid.block_2", ei, ei);
+        v->e_no_g = t.add("encoder.norm_out.weight", PK_VEC, {ei});
+        v->e_no_b = t.add("encoder.norm_out.bias", PK_VEC, {ei});
+        v->e_co_w = t.add("encoder.conv_out.weight", PK_CONV3, {2 * z, ei, 3, 3});
+        v->e_co_b = t.add("encoder.conv_out.bias", PK_VEC, {2 * z});
+        v->e_q_w = t.add("quant_conv.weight", PK_MAT, {2 * z, 2 * z, 1, 1});
+        v->e_q_b = t.add("quant_conv.bias", PK_VEC, {2 * z});
+    }
     return t.finalize();
 }
 
@@ -112,14 +161,16 @@ struct VRun {
     int n;
     half_t* P(int s) const { return v->pt.ptr(s); }
 
-    void conv(const half_t* x, int cin, int Hs, int Ws, int Hv, int Wv, int ksize, int wslot, int bslot, int cout, const half_t* R, half_t* out) {
+    void conv(const half_t* x, int cin, int Hs, int Ws, int Hv, int Wv, int ksize, int wslot, int bslot, int cout, const half_t* R, half_t* out,
+              int stride = 1, int pad = -1, int Ho = 0, int Wo = 0) {
         GemmParams p;
         p.conv = 1;
         p.ksize = ksize;
+        p.pad = pad;
         p.A = x; p.C1 = cin;
-        p.Hs = Hs; p.Ws = Ws; p.Hv = Hv; p.Wv = Wv; p.Ho = Hv; p.Wo = Wv; p.stride = 1;
+        p.Hs = Hs; p.Ws = Ws; p.Hv = Hv; p.Wv = Wv; p.Ho = Ho ? Ho : Hv; p.Wo = Wo ? Wo : Wv; p.stride = stride;
         p.W = P(wslot); p.ldw = ksize * ksize * cin;
-        p.M = n * Hv * Wv; p.N = cout; p.K = ksize * ksize * cin;
+        p.M = n * p.Ho * p.Wo; p.N = cout; p.K = ksize * ksize * cin;
         p.bias_n = P(bslot);
         p.R = R; p.ldr = cout;
         p.C = out; p.ldc = cout;
@@ -150,29 +201,29 @@ struct VRun {
     }
 
     // AttnBlock.forward, LD.py:3630-3642
-    half_t* attn(const half_t* x, int H, int W) {
+    half_t* attn(const VAttnW& aw, const half_t* x, int H, int W) {
         Arena& ar = *ex.arena;
-        const int C = v->block_in0, L = H * W;
+        const int C = aw.c, L = H * W;
         const size_t M = (size_t)n * L;
         half_t* out = ar.halfs(M * C);
         const size_t mk = ar.mark();
         half_t* g = ar.halfs(M * C);
-        ex.groupnorm(x, C, nullptr, 0, n, L, P(v->an_g), P(v->an_b), 1e-6f, 0, g);
+        ex.groupnorm(x, C, nullptr, 0, n, L, P(aw.n_g), P(aw.n_b), 1e-6f, 0, g);
         half_t* qk = ar.halfs(M * 2 * C);
         {
             GemmParams p;
-            p.A = g; p.lda = C; p.W = P(v->aq_w); p.ldw = C;
-            p.M = (int)M; p.N = 2 * C; p.K = C; p.bias_n = P(v->aq_b);
+            p.A = g; p.lda = C; p.W = P(aw.q_w); p.ldw = C;
+            p.M = (int)M; p.N = 2 * C; p.K = C; p.bias_n = P(aw.q_b);
             p.C = qk; p.ldc = 2 * C;
             ex.gemm(p);
         }
         half_t* vt = ar.halfs(M * C);
         {   // V^T[b] = Wv · g_b^T + bv (bias along rows)
             GemmParams p;
-            p.A = P(v->av_w); p.lda = C; p.sA = 0;
+            p.A = P(aw.v_w); p.lda = C; p.sA = 0;
             p.W = g; p.ldw = C; p.sW = (long long)L * C;
             p.M = C; p.N = L; p.K = C; p.batch = n;
-            p.bias_m = P(v->av_b);
+            p.bias_m = P(aw.v_b);
             p.C = vt; p.ldc = L; p.sC = (long long)C * L;
             ex.gemm(p);
         }
@@ -199,8 +250,8 @@ struct VRun {
         }
         {
             GemmParams p;
-            p.A = o; p.lda = C; p.W = P(v->ao_w); p.ldw = C;
-            p.M = (int)M; p.N = C; p.K = C; p.bias_n = P(v->ao_b);
+            p.A = o; p.lda = C; p.W = P(aw.o_w); p.ldw = C;
+            p.M = (int)M; p.N = C; p.K = C; p.bias_n = P(aw.o_b);
             p.R = x; p.ldr = C;
             p.C = out; p.ldc = C;
             ex.gemm(p);
@@ -237,7 +288,7 @@ int run_decode(ld_vae* v, bool dry, const float* z, float* out, int b, int h, in
         if (!dry) ex.note(small_conv_in_launch(a, stream));
     }
     f = R.resblock(v->mid1, f, H, W);
-    f = R.attn(f, H, W);
+    f = R.attn(v->mid_attn, f, H, W);
     f = R.resblock(v->mid2, f, H, W);
     for (int lvl = c.num_levels - 1; lvl >= 0; --lvl) {
         for (const VResW& r : v->up[lvl]) {
@@ -262,6 +313,72 @@ int run_decode(ld_vae* v, bool dry, const float* z, float* out, int b, int h, in
         ex.flops += 2.0 * b * H * W * C * 9.0 * c.out_ch;
         if (!dry) ex.note(small_conv_out_launch(a, stream));
     }
+    v->last_launches = ex.launches;
+    v->last_flops = ex.flops;
+    if (dry_peak) *dry_peak = ar.peak;
+    return ex.status;
+}
+
+// VAE.encode's device part (LD.py:6383-6410 → AutoencodingEngine.encode 3475-3481 → Encoder.forward 3731-3758 → quant_conv):
+// pixels fp32 NCHW [b][3][8h][8w] already mapped to [-1,1]  ->  moments fp32 NCHW [b][2z][h][w] (mean | logvar)
+int run_encode(ld_vae* v, bool dry, const float* px, float* moments, int b, int h, int w, hipStream_t stream, size_t* dry_peak = nullptr) {
+    VRun R;
+    R.v = v;
+    R.n = b;
+    Exec& ex = R.ex;
+    ex.stream = stream;
+    ex.dry = dry;
+    Arena plan;
+    ex.arena = dry ? &plan : &v->arena;
+    ex.splitk_ws = v->splitk_ws;
+    ex.splitk_bytes = v->splitk_bytes;
+    Arena& ar = *ex.arena;
+    ar.release(0);
+    const ld_vae_config& c = v->cfg;
+    int H = h, W = w;
+    for (int l = 1; l < c.num_levels; ++l) {
+        H *= 2;
+        W *= 2;
+    }
+    int C = c.ch;
+    half_t* f = ar.halfs((size_t)b * H * W * C);
+    {
+        SmallConvInArgs a;
+        a.x = px; a.w = v->pt.ptr(v->e_cin_w); a.b = v->pt.ptr(v->e_cin_b); a.y = f;
+        a.N = b; a.Cin = c.out_ch; a.H = H; a.W = W; a.Cout = C;
+        ex.launches += 1;
+        ex.flops += 2.0 * b * H * W * C * 9.0 * c.out_ch;
+        if (!dry) ex.note(small_conv_in_launch(a, stream));
+    }
+    for (int lvl = 0; lvl < c.num_levels; ++lvl) {
+        for (const VResW& r : v->down[lvl]) {
+            f = R.resblock(r, f, H, W);
+            C = r.cout;
+        }
+        if (lvl != c.num_levels - 1) {
+            // Downsample (LD.py:3514-3528): F.pad(0,1,0,1) then 3x3 stride-2 conv without padding = top/left pad 0,
+            // bottom/right zeros supplied by the loader's bounds check
+            const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
+            half_t* o = ar.halfs((size_t)b * Ho * Wo * C);
+            R.conv(f, C, H, W, H, W, 3, v->dwn_w[lvl], v->dwn_b[lvl], C, nullptr, o, 2, 0, Ho, Wo);
+            f = o;
+            H = Ho;
+            W = Wo;
+        }
+    }
+    f = R.resblock(v->e_mid1, f, H, W);
+    f = R.attn(v->e_attn, f, H, W);
+    f = R.resblock(v->e_mid2, f, H, W);
+    {
+        half_t* g = ar.halfs((size_t)b * H * W * C);
+        ex.groupnorm(f, C, nullptr, 0, b, H * W, v->pt.ptr(v->e_no_g), v->pt.ptr(v->e_no_b), 1e-6f, 1, g);
+        const int Z2 = 2 * c.z_channels;
+        half_t* m = ar.halfs((size_t)b * H * W * Z2);
+        R.conv(g, C, H, W, H, W, 3, v->e_co_w, v->e_co_b, Z2, nullptr, m);
+        ex.launches += 1;
+        if (!dry && ex.status == LD_OK) ex.note(small_pointwise_launch(m, v->pt.ptr(v->e_q_w), v->pt.ptr(v->e_q_b), moments, b, H * W, Z2, stream));
+    }
+    if (H != h || W != w) ex.note(LD_ERR_SHAPE);
     v->last_launches = ex.launches;
     v->last_flops = ex.flops;
     if (dry_peak) *dry_peak = ar.peak;
@@ -321,8 +438,14 @@ int ld_vae_reserve(ld_vae* v, int max_b, int max_h, int max_w) {
     v->arena = Arena();
     v->plan_b = v->plan_h = v->plan_w = 0;
     size_t peak = 0;
-    const int st = run_decode(v, true, nullptr, nullptr, max_b, max_h, max_w, nullptr, &peak);
+    int st = run_decode(v, true, nullptr, nullptr, max_b, max_h, max_w, nullptr, &peak);
     if (st != LD_OK) return st;
+    if (v->cfg.with_encoder) {
+        size_t pe = 0;
+        st = run_encode(v, true, nullptr, nullptr, max_b, max_h, max_w, nullptr, &pe);
+        if (st != LD_OK) return st;
+        if (pe > peak) peak = pe;
+    }
     const size_t act = (peak + 4095) / 4096 * 4096;
     v->splitk_bytes = (size_t)64 << 20;
     v->ws_bytes = act + v->splitk_bytes + 4096;
@@ -350,6 +473,19 @@ int ld_vae_decode(ld_vae* v, const float* z, float* out, int b, int h, int w, vo
         v->plan_w = w;
     }
     return run_decode(v, false, z, out, b, h, w, (hipStream_t)stream);
+}
+
+int ld_vae_encode(ld_vae* v, const float* pixels_nchw, float* moments, int b, int h, int w, void* stream) {
+    if (v == nullptr || pixels_nchw == nullptr || moments == nullptr) return LD_ERR_ARG;
+    if (!v->cfg.with_encoder) return LD_ERR_STATE;
+    if (v->ws_base == nullptr || !v->pt.all_loaded()) return LD_ERR_STATE;
+    if (b < 1 || h < 1 || w < 1 || ((h * w) & 7)) return LD_ERR_SHAPE;
+    size_t peak = 0;
+    int st = run_encode(v, true, nullptr, nullptr, b, h, w, nullptr, &peak);
+    if (st != LD_OK) return st;
+    if (peak > v->arena.cap) return LD_ERR_SHAPE;
+    v->plan_b = v->plan_h = v->plan_w = 0;   // the decode plan cache does not cover encode shapes
+    return run_encode(v, false, pixels_nchw, moments, b, h, w, (hipStream_t)stream);
 }
 
 int ld_vae_last_launches(const ld_vae* v) { return v ? v->last_launches : 0; }

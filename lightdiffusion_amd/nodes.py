@@ -109,6 +109,11 @@ class VAEDecode:
         return (vae.decode(samples["samples"]),)
 
 
+class VAEEncode:
+    def encode(self, vae: MI355XVAE, pixels):
+        return ({"samples": vae.encode(pixels[:, :, :, :3])},)
+
+
 def bislerp(samples: torch.Tensor, width: int, height: int) -> torch.Tensor:
     """Latent upscale of the hires-fix path (bislerp, LD.py:429-518): 2-tap separable resize along W then H whose blend of
     the two C-vectors slerps the direction and lerps the magnitude.  Runs once per image (torch ops on `samples.device`)."""
@@ -165,7 +170,7 @@ def load_synthetic(device="cuda:0", max_batch: int = 1, max_hw=(64, 64), tiny: b
         ccfg = dict(ccfg, hidden_size=ucfg["context_dim"])
     gen = lambda name, shape: W.synth_tensor(name, shape, seed)
     unet = MI355XUNet(ucfg, gen, device=device, max_batch=2 * max_batch, max_hw=max_hw)
-    vae = MI355XVAE(vcfg, gen, device=device, max_batch=max_batch, max_hw=max_hw)
+    vae = MI355XVAE(vcfg, gen, device=device, max_batch=max_batch, max_hw=max_hw, with_encoder=True)
     tok = PromptTokenizer.from_pretrained(tokenizer_dir) if tokenizer_dir else None
     clip = CLIP(CLIPTextModel(ccfg, W.synth_state_dict(W.clip_param_shapes(ccfg), seed), device=device), tok)
     return _attach(unet, device), clip, vae
@@ -182,7 +187,8 @@ class CheckpointLoaderSimple:
         from safetensors.torch import load_file
         sd = load_file(ckpt_name)
         unet = MI355XUNet(W.sd15_unet_config(), sd, device=self.device, max_batch=2 * self.max_batch, max_hw=self.max_hw)
-        vae = MI355XVAE(W.sd15_vae_config(), sd, device=self.device, max_batch=self.max_batch, max_hw=self.max_hw)
+        vae = MI355XVAE(W.sd15_vae_config(), sd, device=self.device, max_batch=self.max_batch, max_hw=self.max_hw,
+                        with_encoder=any(k.startswith("first_stage_model.encoder.") for k in sd))
         pre = "cond_stage_model.transformer."
         csd = {}
         for k, v in sd.items():

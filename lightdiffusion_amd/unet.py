@@ -162,10 +162,12 @@ class MI355XVAE:
     downscale_ratio = 8
     latent_channels = 4
 
-    def __init__(self, cfg: dict, weights: WeightSource, device="cuda:0", max_batch: int = 1, max_hw=(64, 64)):
+    def __init__(self, cfg: dict, weights: WeightSource, device="cuda:0", max_batch: int = 1, max_hw=(64, 64), with_encoder: bool = False):
         self.cfg = dict(cfg)
         self.device = torch.device(device)
+        self.with_encoder = bool(with_encoder)
         c = VAEConfig()
+        c.with_encoder = int(self.with_encoder)
         c.z_channels, c.ch, c.num_levels = cfg["z_channels"], cfg["ch"], len(cfg["ch_mult"])
         for i, v in enumerate(cfg["ch_mult"]):
             c.ch_mult[i] = v
@@ -208,6 +210,30 @@ class MI355XVAE:
     def decode(self, samples_in: torch.Tensor) -> torch.Tensor:
         """VAE.decode (LD.py:6357-6381): returns [B, 8h, 8w, 3] fp32 in [0,1] on the CPU (`intermediate_device`)."""
         return self.decode_device(samples_in).cpu()
+
+    def encode_moments(self, pixel_samples: torch.Tensor) -> torch.Tensor:
+        """pixels [B, H, W, 3] in [0,1] -> moments [B, 2z, H/8, W/8] fp32 on the device (mean | logvar): everything of
+        VAE.encode (LD.py:6383-6410) up to, but excluding, the regularizer's random sample."""
+        if not self.with_encoder:
+            raise RuntimeError("this MI355XVAE was created without the encoder (with_encoder=True)")
+        px = pixel_samples[..., :3].to(self.device, torch.float32).movedim(-1, 1)
+        px = (px * 2.0 - 1.0).contiguous()                                   # process_input, LD.py:6295
+        b, _, H, W = px.shape
+        h, w = H // 8, W // 8
+        if h * 8 != H or w * 8 != W:
+            raise ValueError("image sides must be multiples of 8")
+        out = torch.empty(b, 2 * self.cfg["z_channels"], h, w, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().ld_vae_encode(self._h, px.data_ptr(), out.data_ptr(), b, h, w, _stream()), "ld_vae_encode")
+        return out
+
+    def encode(self, pixel_samples: torch.Tensor) -> torch.Tensor:
+        """VAE.encode (LD.py:6383-6410): [B,H,W,3] in [0,1] -> latent [B,4,H/8,W/8] fp32 on the CPU.  The posterior sample
+        (DiagonalGaussianDistribution.sample, LD.py:175-179) draws torch.randn on the HOST global generator, as the reference does."""
+        m = self.encode_moments(pixel_samples).cpu()
+        mean, logvar = torch.chunk(m, 2, dim=1)
+        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+        return mean + std * torch.randn(mean.shape)
 
 
 def synthetic_unet(cfg: Optional[dict] = None, seed: int = 0, **kw) -> MI355XUNet:

@@ -179,6 +179,47 @@ def vae_decoder_param_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
     return shp
 
 
+def vae_encoder_param_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
+    """name -> shape for `encoder.*` + `quant_conv` (LD.py:3649-3758, 3468)."""
+    ch, cm, nrb, z = cfg["ch"], cfg["ch_mult"], cfg["num_res_blocks"], cfg["z_channels"]
+    shp: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(p, o, i, k):
+        shp[p + ".weight"] = (o, i, k, k)
+        shp[p + ".bias"] = (o,)
+
+    def norm(p, c):
+        shp[p + ".weight"] = (c,)
+        shp[p + ".bias"] = (c,)
+
+    def res(p, cin, cout):
+        norm(p + ".norm1", cin)
+        conv(p + ".conv1", cout, cin, 3)
+        norm(p + ".norm2", cout)
+        conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(p + ".nin_shortcut", cout, cin, 1)
+
+    conv("encoder.conv_in", ch, cfg["out_ch"], 3)
+    bi = ch
+    for lvl in range(len(cm)):
+        bo = ch * cm[lvl]
+        for b in range(nrb):
+            res(f"encoder.down.{lvl}.block.{b}", bi, bo)
+            bi = bo
+        if lvl != len(cm) - 1:
+            conv(f"encoder.down.{lvl}.downsample.conv", bi, bi, 3)
+    res("encoder.mid.block_1", bi, bi)
+    norm("encoder.mid.attn_1.norm", bi)
+    for n in ("q", "k", "v", "proj_out"):
+        conv(f"encoder.mid.attn_1.{n}", bi, bi, 1)
+    res("encoder.mid.block_2", bi, bi)
+    norm("encoder.norm_out", bi)
+    conv("encoder.conv_out", 2 * z, bi, 3)
+    conv("quant_conv", 2 * z, 2 * z, 1)
+    return shp
+
+
 def clip_param_shapes(cfg: dict) -> Dict[str, Tuple[int, ...]]:
     """name -> shape for CLIPTextModel (LD.py:4268-4487), keys as under `transformer.`."""
     h, f = cfg["hidden_size"], cfg["intermediate_size"]

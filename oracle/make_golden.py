@@ -216,6 +216,22 @@ def g_vae():
             save("vae_tiny", z=z, img=img)
 
 
+# ------------------------------------------------------------------ 5b. VAE encoder (through the reference's own VAE.encode arithmetic)
+def g_vae_enc():
+    for tag, cfg, hw in (("tiny", W.tiny_vae_config(), (64, 48)), ("sd15", W.sd15_vae_config(), (256, 256))):
+        kw = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=cfg["ch"], ch_mult=cfg["ch_mult"],
+                  num_res_blocks=cfg["num_res_blocks"], attn_resolutions=[], dropout=0.0)
+        eng = ref.AutoencodingEngine(ref.Encoder(**kw), ref.Decoder(**kw), ref.DiagonalGaussianRegularizer(sample=True))
+        sd = eng.state_dict()
+        eng.load_state_dict({k: W.synth_tensor(k, tuple(v.shape)) for k, v in sd.items()}, strict=True)
+        px = torch.rand((1,) + hw + (3,), generator=torch.Generator().manual_seed(57))
+        x = px.movedim(-1, 1) * 2.0 - 1.0                       # VAE.process_input, LD.py:6295
+        moments = eng.quant_conv(eng.encoder(x))
+        torch.manual_seed(58)
+        z = eng.encode(x)                                        # regularizer sample on the host generator
+        save(f"vae_enc_{tag}", pixels=px, moments=moments, z_seed58=z)
+
+
 # ------------------------------------------------------------------ 6. CLIP + prompt weights
 def g_clip():
     cfg = W.tiny_clip_config()
@@ -275,6 +291,6 @@ def g_bislerp():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "blocks", "unets", "samplers", "vae", "clip", "tokens", "bislerp"]
+    which = sys.argv[1:] or ["schedules", "blocks", "unets", "samplers", "vae", "vae_enc", "clip", "tokens", "bislerp"]
     for n in which:
         globals()["g_" + n]()

@@ -360,6 +360,29 @@ def vae_decode(sd: SD, cfg: dict, z: torch.Tensor) -> torch.Tensor:
     return torch.clamp((h + 1.0) / 2.0, 0.0, 1.0).movedim(1, -1)
 
 
+def vae_encode_moments(sd: SD, cfg: dict, pixels: torch.Tensor) -> torch.Tensor:
+    """VAE.encode up to the regularizer (LD.py:6383-6410 ∘ AutoencodingEngine.encode 3475-3481 ∘ Encoder.forward 3731-3758):
+    pixels [B,H,W,3] in [0,1] -> moments [B,2z,H/8,W/8] (mean | logvar)."""
+    h = _conv(pixels[..., :3].movedim(-1, 1) * 2.0 - 1.0, sd, "encoder.conv_in")
+    nl = len(cfg["ch_mult"])
+    for lvl in range(nl):
+        for b in range(cfg["num_res_blocks"]):
+            h = vae_resblock(h, sd, f"encoder.down.{lvl}.block.{b}")
+        if lvl != nl - 1:      # Downsample, LD.py:3514-3528: zero-pad right/bottom by one, 3x3 stride 2, no padding
+            h = _conv(F.pad(h, (0, 1, 0, 1)), sd, f"encoder.down.{lvl}.downsample.conv", stride=2, padding=0)
+    h = vae_resblock(h, sd, "encoder.mid.block_1")
+    h = vae_attn(h, sd, "encoder.mid.attn_1")
+    h = vae_resblock(h, sd, "encoder.mid.block_2")
+    h = _conv(F.silu(_gn(h, sd, "encoder.norm_out", 1e-6)), sd, "encoder.conv_out")
+    return _conv(h, sd, "quant_conv", padding=0)
+
+
+def vae_sample(moments: torch.Tensor) -> torch.Tensor:
+    """DiagonalGaussianDistribution.sample (LD.py:166-179): mean + std * randn from the host global generator."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    return mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * torch.randn(mean.shape)
+
+
 # ======================================================================== CLIP-L (SURVEY §8 a17)
 
 def clip_text_model(sd: SD, cfg: dict, tokens: torch.Tensor, layer_idx: Optional[int] = -2) -> torch.Tensor:

@@ -94,3 +94,20 @@ def test_vae_sd15_golden():
     assert img.shape == (1, 256, 256, 3)
     assert float((img[:, ::4, ::4] - g["img_sub"]).abs().max()) < 2.0 / 255.0
     assert abs(float(img.mean() - g["mean"])) < 1e-3
+
+
+@pytest.mark.parametrize("tag,hw", [("tiny", (8, 6)), ("sd15", (32, 32))])
+def test_vae_encode_golden(tag, hw):
+    """VAE.encode: moments against the reference's Encoder + quant_conv; sample with the host generator."""
+    from lightdiffusion_amd.unet import synthetic_vae
+    g = load_golden("vae_enc_" + tag)
+    cfg = W.tiny_vae_config() if tag == "tiny" else W.sd15_vae_config()
+    v = synthetic_vae(cfg, max_batch=1, max_hw=hw, with_encoder=True)
+    m = v.encode_moments(g["pixels"]).cpu()
+    assert m.shape == g["moments"].shape
+    assert rel_l2(m, g["moments"]) < 5e-3
+    torch.manual_seed(58)
+    z = v.encode(g["pixels"])
+    assert z.device.type == "cpu" and rel_l2(z, g["z_seed58"]) < 5e-3
+    img = v.decode(z)                                   # round trip through the decoder still works on the same handle
+    assert img.shape == g["pixels"].shape and torch.isfinite(img).all()

@@ -190,3 +190,14 @@ def test_bislerp():
     g = load_golden("bislerp")
     assert rel_l2(O.bislerp(g["x"], 12, 16), g["y2x"]) < 2e-6
     assert rel_l2(O.bislerp(g["x"], 9, 11), g["y_odd"]) < 2e-6
+
+
+@pytest.mark.parametrize("tag", ["tiny", "sd15"])
+def test_vae_encode(tag):
+    g = load_golden("vae_enc_" + tag)
+    cfg = W.tiny_vae_config() if tag == "tiny" else W.sd15_vae_config()
+    sd = W.synth_state_dict(W.vae_encoder_param_shapes(cfg))
+    m = O.vae_encode_moments(sd, cfg, g["pixels"])
+    assert rel_l2(m, g["moments"]) < 2e-5
+    torch.manual_seed(58)
+    assert rel_l2(O.vae_sample(m), g["z_seed58"]) < 2e-5
