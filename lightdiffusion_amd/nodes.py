@@ -177,26 +177,26 @@ def load_synthetic(device="cuda:0", max_batch: int = 1, max_hw=(64, 64), tiny: b
 
 
 class CheckpointLoaderSimple:
-    """load_checkpoint(ckpt) -> (model, clip, vae) from a single-file SD1.x safetensors (key layout LD.py:5921-5922,
-    5980-6009, 6446-6465).  Only the SD1.5 architecture (the reference's sm_SD15) is recognised."""
+    """load_checkpoint(ckpt) -> (model, clip, vae) from a single-file SD1.x checkpoint (LD.py:6426-6513, 6591-6601): the
+    architecture is detected from the keys (checkpoint.detect_*), weights are repacked on the device by the C library."""
 
-    def __init__(self, device="cuda:0", max_batch: int = 1, max_hw=(64, 64), tokenizer_dir: Optional[str] = None):
+    def __init__(self, device="cuda:0", max_batch: int = 1, max_hw=(64, 64), tokenizer_dir: Optional[str] = None,
+                 clip_heads: int = 12, unet_heads: int = 8):
         self.device, self.max_batch, self.max_hw, self.tokenizer_dir = device, max_batch, max_hw, tokenizer_dir
+        self.clip_heads, self.unet_heads = clip_heads, unet_heads
 
-    def load_checkpoint(self, ckpt_name, output_vae=True, output_clip=True):
-        from safetensors.torch import load_file
-        sd = load_file(ckpt_name)
-        unet = MI355XUNet(W.sd15_unet_config(), sd, device=self.device, max_batch=2 * self.max_batch, max_hw=self.max_hw)
-        vae = MI355XVAE(W.sd15_vae_config(), sd, device=self.device, max_batch=self.max_batch, max_hw=self.max_hw,
-                        with_encoder=any(k.startswith("first_stage_model.encoder.") for k in sd))
-        pre = "cond_stage_model.transformer."
-        csd = {}
-        for k, v in sd.items():
-            if k.startswith(pre):
-                k2 = k[len(pre):]
-                csd[k2 if k2.startswith("text_model.") else "text_model." + k2] = v
+    def load_checkpoint(self, ckpt_name, output_vae=True, output_clip=True, lora: Optional[dict] = None, lora_strength: float = 1.0):
+        from . import checkpoint as CK
+        sd = CK.load_state_dict(ckpt_name) if isinstance(ckpt_name, str) else dict(ckpt_name)
+        if lora:
+            CK.merge_lora(sd, lora, lora_strength)
+        unet = MI355XUNet(CK.detect_unet_config(sd, num_heads=self.unet_heads), sd, device=self.device, max_batch=2 * self.max_batch,
+                          max_hw=self.max_hw)
+        vcfg, has_enc = CK.detect_vae_config(sd)
+        vae = MI355XVAE(vcfg, sd, device=self.device, max_batch=self.max_batch, max_hw=self.max_hw, with_encoder=has_enc)
+        csd = CK.clip_state_dict(sd)
         tok = PromptTokenizer.from_pretrained(self.tokenizer_dir) if self.tokenizer_dir else None
-        clip = CLIP(CLIPTextModel(W.sd15_clip_config(), csd, device=self.device), tok)
+        clip = CLIP(CLIPTextModel(CK.detect_clip_config(csd, self.clip_heads), csd, device=self.device), tok)
         return _attach(unet, self.device), clip, vae
 
 

@@ -196,6 +196,79 @@ def sample_dpmpp_2m_sde(model, x, sigmas, extra_args=None, callback=None, disabl
     return x
 
 
+class _PIDStep:
+    """PID step-size controller of DPM-Solver-12/23 (LD.py:944-973): h <- h * limiter(prod inv_err_k ** b_k)."""
+
+    def __init__(self, h, pcoeff, icoeff, dcoeff, order, accept_safety, eps=1e-8):
+        self.h, self.accept_safety, self.eps = h, accept_safety, eps
+        self.b = ((pcoeff + icoeff + dcoeff) / order, -(pcoeff + 2 * dcoeff) / order, dcoeff / order)
+        self.hist = None
+
+    def propose(self, error: float) -> bool:
+        inv = 1.0 / (float(error) + self.eps)
+        if self.hist is None:
+            self.hist = [inv, inv, inv]
+        self.hist[0] = inv
+        factor = self.hist[0] ** self.b[0] * self.hist[1] ** self.b[1] * self.hist[2] ** self.b[2]
+        factor = 1 + math.atan(factor - 1)
+        accept = factor >= self.accept_safety
+        if accept:
+            self.hist[2], self.hist[1] = self.hist[1], self.hist[0]
+        self.h = self.h * factor
+        return accept
+
+
+@torch.no_grad()
+def sample_dpm_adaptive(model, x, sigma_min, sigma_max, extra_args=None, callback=None, disable=None, order=3, rtol=0.05, atol=0.0078,
+                        h_init=0.05, pcoeff=0.0, icoeff=1.0, dcoeff=0.0, accept_safety=0.81, eta=0.0, s_noise=1.0,
+                        noise_sampler=None, return_info=False):
+    """DPM-Solver-12/23 with adaptive steps (LD.py:976-1170) — the reference GUI's default sampler (LD.py:10572-10576).
+    Three UNet evaluations per proposed step (eps at s, at s + h/3, at s + 2h/3; the 2nd-order estimate shares the first
+    two), embedded error estimate, PID step control in t = -log(sigma).  The reference's variant adds no noise (su = 0)."""
+    if sigma_min <= 0 or sigma_max <= 0:
+        raise ValueError("sigma_min and sigma_max must not be 0")
+    extra_args = {} if extra_args is None else extra_args
+    sig = lambda t: (-t).exp()                                       # t is a 0-dim fp32 tensor, like the reference's
+    ones = x.new_ones([x.shape[0]])
+
+    def eps_at(xx, t):
+        s = sig(t)
+        return (xx - model(xx, float(s) * ones, **extra_args)) / float(s)
+
+    t_start, t_end = -torch.tensor(float(sigma_max)).log(), -torch.tensor(float(sigma_min)).log()
+    forward = bool(t_end > t_start)
+    pid = _PIDStep(abs(h_init) * (1 if forward else -1), pcoeff, icoeff, dcoeff, 1.5 if eta else order, accept_safety)
+    atol_t, rtol_t = torch.tensor(atol, device=x.device), torch.tensor(rtol, device=x.device)
+    s, x_prev = t_start, x
+    info = {"steps": 0, "nfe": 0, "n_accept": 0, "n_reject": 0}
+    r1, r2 = 1.0 / 3.0, 2.0 / 3.0
+    while (s < t_end - 1e-5) if forward else (s > t_end + 1e-5):
+        if _interrupted(extra_args):
+            break
+        t = torch.minimum(t_end, s + pid.h) if forward else torch.maximum(t_end, s + pid.h)
+        h = t - s
+        e0 = eps_at(x, s)
+        s1, s2 = s + r1 * h, s + r2 * h
+        u1 = x - float(sig(s1) * (r1 * h).expm1()) * e0
+        e1 = eps_at(u1, s1)
+        x_low = x - float(sig(t) * h.expm1()) * e0 - float(sig(t) / (2 * r1) * h.expm1()) * (e1 - e0)
+        u2 = x - float(sig(s2) * (r2 * h).expm1()) * e0 - float(sig(s2) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1)) * (e1 - e0)
+        e2 = eps_at(u2, s2)
+        x_high = x - float(sig(t) * h.expm1()) * e0 - float(sig(t) / r2 * (h.expm1() / h - 1)) * (e2 - e0)
+        delta = torch.maximum(atol_t, rtol_t * torch.maximum(x_low.abs(), x_prev.abs()))
+        error = float(torch.linalg.norm((x_low - x_high) / delta) / x.numel() ** 0.5)
+        if pid.propose(error):
+            x_prev, x, s = x_low, x_high, t
+            info["n_accept"] += 1
+        else:
+            info["n_reject"] += 1
+        info["nfe"] += order
+        info["steps"] += 1
+        if callback is not None:
+            callback({"x": x, "i": info["steps"], "sigma": float(sig(s)), "denoised": None})
+    return (x, info) if return_info else x
+
+
 # ------------------------------------------------------------------ guidance
 def convert_cond(cond):
     """LD.py:2287-2297 (cond = [[tensor, {..}], ...])."""
@@ -278,7 +351,12 @@ def ksampler(sampler_name, extra_options=None, inpaint_options=None):
         fn = lambda model, noise, sigmas, extra_args, callback, disable, **o: sample_dpmpp_2m_sde(
             model, noise, sigmas, extra_args=extra_args, callback=callback, disable=disable, **o)
     elif sampler_name == "dpm_adaptive":
-        raise NotImplementedError("dpm_adaptive (LD.py:976-1170) is outside the hot-path scope (SURVEY §8f rank 4)")
+        def fn(model, noise, sigmas, extra_args, callback, disable, **o):     # dpm_adaptive_function, LD.py:2777-2797
+            if len(sigmas) <= 1:
+                return noise
+            sigma_min = sigmas[-1] if sigmas[-1] != 0 else sigmas[-2]
+            return sample_dpm_adaptive(model, noise, float(sigma_min), float(sigmas[0]), extra_args=extra_args, callback=callback,
+                                       disable=disable, **o)
     else:
         raise ValueError(f"unknown sampler '{sampler_name}'")
     return KSAMPLER(fn, extra_options, inpaint_options)

@@ -40,7 +40,7 @@ _DEFS = {
     # schedules / samplers (LD.py:787-1244)
     "make_beta_schedule", "checkpoint", "timestep_embedding", "zero_module", "append_zero",
     "get_sigmas_karras", "to_d", "get_ancestral_step", "default_noise_sampler",
-    "sample_euler_ancestral", "sample_dpmpp_2m_sde",
+    "sample_euler_ancestral", "sample_dpmpp_2m_sde", "PIDStepSizeController", "DPMSolver", "sample_dpm_adaptive",
     "TimestepBlock1", "TimestepEmbedSequential1", "EPS", "ModelSamplingDiscrete",
     # sampling core (LD.py:2282-3203)
     "get_models_from_cond", "convert_cond", "get_additional_models", "prepare_sampling", "cleanup_models",
@@ -73,6 +73,25 @@ _ASSIGNS = {"ops", "oai_ops", "ae_ops", "ACTIVATIONS", "_ATTN_PRECISION", "KSAMP
             "SCHEDULER_NAMES", "SAMPLER_NAMES", "PROGRESS_BAR_ENABLED"}
 
 
+class _NullBar:
+    """tqdm stand-in: usable as `tqdm(iterable)` and as `with tqdm(disable=..) as pbar: pbar.update()` (LD.py:1143-1144)."""
+
+    def __init__(self, it=None, **_k):
+        self.it = it
+
+    def __iter__(self):
+        return iter(self.it)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def update(self, *a, **k):
+        return None
+
+
 class _StubApp:
     """Stands in for the Tk `app` global the sampler loops poll (LD.py:922-937)."""
     interrupt_flag = False
@@ -97,7 +116,7 @@ def load_reference(path: str = REF_PATH) -> types.SimpleNamespace:
         "torch": torch, "th": th, "nn": nn, "F": F, "math": math, "np": np, "logging": logging,
         "rearrange": rearrange, "collections": collections, "threading": threading,
         "abstractmethod": abstractmethod, "Enum": Enum, "Union": Union, "Tuple": Tuple,
-        "trange": lambda n, disable=None: range(n), "tqdm": lambda it, **k: it,
+        "trange": lambda n, disable=None: range(n), "tqdm": _NullBar,
         "app": _StubApp(),
         # stubs for the device / memory manager (LD.py:1362-2265, out of scope): CPU, never offload
         "xformers_enabled": lambda: False, "xformers_enabled_vae": lambda: False,

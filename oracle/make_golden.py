@@ -196,6 +196,13 @@ def g_samplers():
     out["toy_dpmpp2m_heun"] = ref.sample_dpmpp_2m_sde(toy, x0, ref.get_sigmas_karras(8, 0.03, 14.6), extra_args={}, eta=0.0,
                                                       solver_type="heun", noise_sampler=never)
     out["toy_x0"] = x0
+    xa, info = ref.sample_dpm_adaptive(toy, x0, 0.03, 14.6, extra_args={}, return_info=True)
+    out["toy_dpm_adaptive"] = xa
+    out["toy_dpm_adaptive_info"] = np.array([info["steps"], info["nfe"], info["n_accept"], info["n_reject"]])
+    # (g) dpm_adaptive (the GUI default, LD.py:10572-10576) through the reference's ksampler on the tiny UNet
+    r = ref.sample(patcher, noise, pos, neg, 7.0, cpu, ref.ksampler("dpm_adaptive"), sig, patcher.model_options,
+                   latent_image=lat["samples"], seed=99)
+    out["dpm_adaptive_tiny"] = r
     save("samplers", **out)
 
 

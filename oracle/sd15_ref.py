@@ -296,6 +296,53 @@ def sample_dpmpp_2m_sde(model: Callable, x, sigmas, eta=1.0, s_noise=1.0, noise_
     return x
 
 
+def sample_dpm_adaptive(model: Callable, x, sigma_min, sigma_max, order=3, rtol=0.05, atol=0.0078, h_init=0.05, pcoeff=0.0,
+                        icoeff=1.0, dcoeff=0.0, accept_safety=0.81, eta=0.0):
+    """sample_dpm_adaptive / DPMSolver.dpm_solver_adaptive / PIDStepSizeController, LD.py:944-1170 (no-noise variant: su = 0).
+    Returns (x, info)."""
+    sig = lambda t: t.neg().exp()
+    ones = x.new_ones([x.shape[0]])
+    eps_at = lambda xx, t: (xx - model(xx, sig(t) * ones)) / sig(t)
+    t0, t1 = -torch.tensor(sigma_max).log(), -torch.tensor(sigma_min).log()
+    fwd = bool(t1 > t0)
+    h_step = abs(h_init) * (1 if fwd else -1)
+    od = 1.5 if eta else order
+    b1, b2, b3 = (pcoeff + icoeff + dcoeff) / od, -(pcoeff + 2 * dcoeff) / od, dcoeff / od
+    errs: List[float] = []
+    s, x_prev = t0, x
+    info = {"steps": 0, "nfe": 0, "n_accept": 0, "n_reject": 0}
+    while (s < t1 - 1e-5) if fwd else (s > t1 + 1e-5):
+        t = torch.minimum(t1, s + h_step) if fwd else torch.maximum(t1, s + h_step)
+        h = t - s
+        e0 = eps_at(x, s)
+        r1, r2 = 1 / 3, 2 / 3                      # both estimates use r1 = 1/3, so they share eps(s) and eps(s + h/3)
+        sa, sb = s + r1 * h, s + r2 * h
+        u1 = x - sig(sa) * (r1 * h).expm1() * e0
+        e1 = eps_at(u1, sa)
+        x_lo = x - sig(t) * h.expm1() * e0 - sig(t) / (2 * r1) * h.expm1() * (e1 - e0)                 # dpm_solver_2_step
+        u2 = x - sig(sb) * (r2 * h).expm1() * e0 - sig(sb) * (r2 / r1) * ((r2 * h).expm1() / (r2 * h) - 1) * (e1 - e0)
+        e2 = eps_at(u2, sb)
+        x_hi = x - sig(t) * h.expm1() * e0 - sig(t) / r2 * (h.expm1() / h - 1) * (e2 - e0)             # dpm_solver_3_step
+        delta = torch.maximum(torch.tensor(atol), torch.tensor(rtol) * torch.maximum(x_lo.abs(), x_prev.abs()))
+        err = float(torch.linalg.norm((x_lo - x_hi) / delta) / x.numel() ** 0.5)
+        inv = 1 / (err + 1e-8)
+        if not errs:
+            errs = [inv, inv, inv]
+        errs[0] = inv
+        f = 1 + math.atan(errs[0] ** b1 * errs[1] ** b2 * errs[2] ** b3 - 1)
+        ok = f >= accept_safety
+        if ok:
+            errs[2], errs[1] = errs[1], errs[0]
+            x_prev, x, s = x_lo, x_hi, t
+            info["n_accept"] += 1
+        else:
+            info["n_reject"] += 1
+        h_step = h_step * f
+        info["nfe"] += order
+        info["steps"] += 1
+    return x, info
+
+
 LATENT_SCALE = 0.18215        # SD15.scale_factor LD.py:137-147
 
 
@@ -318,6 +365,9 @@ def ksample(denoise: Callable, ms: ModelSampling, seed: int, steps: int, cfg: fl
         x = sample_euler_ancestral(model, x, sigmas, **opts)
     elif sampler_name == "dpmpp_2m_sde":
         x = sample_dpmpp_2m_sde(model, x, sigmas, **opts)
+    elif sampler_name == "dpm_adaptive":                                     # dpm_adaptive_function, LD.py:2777-2797
+        smin = sigmas[-1] if sigmas[-1] != 0 else sigmas[-2]
+        x = sample_dpm_adaptive(model, x, float(smin), float(sigmas[0]), **opts)[0]
     else:
         raise ValueError(sampler_name)
     return x.float() / LATENT_SCALE                                         # process_latent_out LD.py:2965

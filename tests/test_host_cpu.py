@@ -80,8 +80,7 @@ def test_node_surface_shapes_and_errors():
     assert lat.shape == (3, 4, 96, 64) and float(lat.abs().sum()) == 0.0
     with pytest.raises(ValueError):
         sampling.ksampler("ddim")
-    with pytest.raises(NotImplementedError):
-        sampling.ksampler("dpm_adaptive")
+    assert sampling.ksampler("dpm_adaptive").sampler_function is not None
     ctx = sampling._cat_ctx([torch.zeros(1, 77, 8), torch.ones(1, 154, 8)])      # lcm padding by repetition (LD.py:647-663)
     assert ctx.shape == (2, 154, 8)
 
@@ -132,3 +131,33 @@ def test_world_size_2_gloo():
         p.join(60)
     assert [r[1] for r in res] == [True, True]
     assert [r[2] for r in res] == [(0, 3), (3, 5)]
+
+
+def _synthetic_checkpoint(tiny=True):
+    ucfg, vcfg, ccfg = W.tiny_unet_config(), W.tiny_vae_config(), W.tiny_clip_config()
+    sd = {}
+    sd.update({"model.diffusion_model." + k: v.half() for k, v in W.synth_state_dict(W.unet_param_shapes(ucfg)).items()})
+    vshapes = dict(W.vae_decoder_param_shapes(vcfg), **W.vae_encoder_param_shapes(vcfg))
+    sd.update({"first_stage_model." + k: v for k, v in W.synth_state_dict(vshapes).items()})
+    sd.update({"cond_stage_model.transformer." + k: v for k, v in W.synth_state_dict(W.clip_param_shapes(ccfg)).items()})
+    return sd, ucfg, vcfg, ccfg
+
+
+def test_checkpoint_config_detection_and_lora_merge():
+    from lightdiffusion_amd import checkpoint as CK
+    sd, ucfg, vcfg, ccfg = _synthetic_checkpoint()
+    assert CK.detect_unet_config(sd) == ucfg
+    full = {"model.diffusion_model." + k: torch.empty(s, device="meta") for k, s in W.unet_param_shapes(W.sd15_unet_config()).items()}
+    assert CK.detect_unet_config(full) == W.sd15_unet_config()          # the real SD1.5 layout (LD.py:6065-6182 result)
+    got, has_enc = CK.detect_vae_config(sd)
+    assert got == vcfg and has_enc
+    csd = CK.clip_state_dict(sd)
+    assert CK.detect_clip_config(csd, num_heads=4) == ccfg
+    key = "model.diffusion_model.input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight"
+    before = sd[key].float().clone()
+    up, down = torch.randn(64, 4), torch.randn(4, 64)
+    name = "lora_unet_input_blocks_1_1_transformer_blocks_0_attn1_to_q"
+    n = CK.merge_lora(sd, {name + ".lora_up.weight": up, name + ".lora_down.weight": down, name + ".alpha": torch.tensor(2.0)}, 0.5)
+    assert n == 1 and torch.allclose(sd[key].float(), before + 0.5 * (2.0 / 4) * (up @ down), atol=2e-3)
+    with pytest.raises(ValueError):
+        CK.detect_unet_config({"foo": torch.zeros(1)})

@@ -157,6 +157,20 @@ def test_toy_sampler_trajectories():
     assert rel_l2(O.sample_dpmpp_2m_sde(toy, g["toy_x0"], sig, eta=0.0, solver_type="heun"), g["toy_dpmpp2m_heun"]) < 1e-6
 
 
+def test_dpm_adaptive():
+    g = load_golden("samplers")
+    toy = lambda x, s: x * (1.0 / (1.0 + s.view(-1, 1, 1, 1) ** 2))
+    x, info = O.sample_dpm_adaptive(toy, g["toy_x0"], 0.03, 14.6)
+    assert [info["steps"], info["nfe"], info["n_accept"], info["n_reject"]] == g["toy_dpm_adaptive_info"].tolist()
+    assert rel_l2(x, g["toy_dpm_adaptive"]) < 1e-5
+    cfg = W.tiny_unet_config()
+    sd = W.synth_state_dict(W.unet_param_shapes(cfg))
+    ms = O.ModelSampling()
+    den = lambda xx, ss, cc: O.apply_model(sd, cfg, ms, xx, ss, cc)
+    y = O.ksample(den, ms, 99, 6, 7.0, "dpm_adaptive", "karras", g["pos"], g["neg"], torch.zeros(1, 4, 12, 16))
+    assert rel_l2(y, g["dpm_adaptive_tiny"]) < 1e-3
+
+
 def test_vae_decode():
     g = load_golden("vae_tiny")
     cfg = W.tiny_vae_config()

@@ -72,6 +72,28 @@ def test_toy_trajectories_on_device():
     assert rel_l2(S.sample_dpmpp_2m_sde(toy, x0, sig, eta=0.0, solver_type="heun").cpu(), g["toy_dpmpp2m_heun"]) < 1e-5
 
 
+def test_dpm_adaptive(stack):
+    """The GUI-default sampler (LD.py:10572-10576): toy denoiser exactly; tiny UNet through ksampler("dpm_adaptive").
+    The PID controller makes accept/reject decisions on an error estimate, so fp16 rounding can move a step boundary:
+    the end latent is held to the looser trajectory tolerance."""
+    from lightdiffusion_amd import sampling as S
+    g = load_golden("samplers")
+    toy = lambda x, s, **kw: x * (1.0 / (1.0 + s.view(-1, 1, 1, 1) ** 2))
+    x, info = S.sample_dpm_adaptive(toy, g["toy_x0"].to(DEV), 0.03, 14.6, return_info=True)
+    assert [info["steps"], info["nfe"], info["n_accept"], info["n_reject"]] == g["toy_dpm_adaptive_info"].tolist()
+    assert rel_l2(x.cpu(), g["toy_dpm_adaptive"]) < 1e-4
+    model = stack[0]
+    pos, neg = conds(g)
+    lat = torch.zeros(1, 4, 12, 16)
+    sig = S.calculate_sigmas(model.get_model_object("model_sampling"), "karras", 6)
+    noise = S.prepare_noise(lat, 99)
+    out = S.sample(model, noise, pos, neg, 7.0, model.load_device, S.ksampler("dpm_adaptive"), sig, model.model_options,
+                   latent_image=lat, seed=99).cpu()
+    assert rel_l2(out, g["dpm_adaptive_tiny"]) < TRAJ_TOL
+    with pytest.raises(ValueError):
+        S.sample_dpm_adaptive(toy, g["toy_x0"].to(DEV), 0.0, 14.6)
+
+
 def test_graph_replay_equals_eager(stack):
     from lightdiffusion_amd.pipeline import CFGDenoiser
     unet = stack[0].model.diffusion_model
@@ -100,3 +122,22 @@ def test_txt2img_end_to_end_tiny(stack):
     img2 = nodes.txt2img(model, clip.clone(), vae, toks, neg, width=128, height=128, batch_size=2, seed=5, steps=4, cfg=6.0,
                          sampler_name="euler_ancestral", scheduler="normal")
     assert torch.equal(img, img2)
+
+
+def test_checkpoint_loader_roundtrip(stack, tmp_path):
+    """CheckpointLoaderSimple on a synthetic single-file safetensors == the directly constructed synthetic stack."""
+    from safetensors.torch import save_file
+    from lightdiffusion_amd import nodes
+    from test_host_cpu import _synthetic_checkpoint
+    sd, ucfg, vcfg, ccfg = _synthetic_checkpoint()
+    path = str(tmp_path / "tiny_sd15.safetensors")
+    save_file({k: v.contiguous() for k, v in sd.items()}, path)
+    model, clip, vae = nodes.CheckpointLoaderSimple(DEV, max_batch=2, max_hw=(16, 16), clip_heads=4).load_checkpoint(path)
+    g = load_golden("unet_tiny_16x16")
+    a, b = model.model.diffusion_model, stack[0].model.diffusion_model
+    for u in (a, b):
+        u.set_context(g["ctx"])
+    ya, yb = a.forward(g["x"].to(DEV), g["sigma"].to(DEV)), b.forward(g["x"].to(DEV), g["sigma"].to(DEV))
+    assert torch.equal(ya, yb)
+    z = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(3))
+    assert torch.equal(vae.decode(z), stack[2].decode(z))
