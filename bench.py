@@ -57,12 +57,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % max(ndev, 1))      # (rehearsals put several ranks on one GPU; the driver gives one each)
+    torch.cuda.set_device(dev)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("LD_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from lightdiffusion_amd import ops, sampling
     from lightdiffusion_amd import weights as W
