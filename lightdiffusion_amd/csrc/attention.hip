@@ -20,8 +20,8 @@ namespace {
 
 constexpr int AT_THREADS = 256;
 
-template <int DK, int KT_KEYS, int SMX = 1>   // KT_KEYS: keys per LDS tile (64 or 128); SMX: softmax code variant (A/B)
-__global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams p) {
+template <int DK, int KT_KEYS, int SMX = 1, int WPS = 1>   // KT_KEYS: keys per LDS tile; SMX: softmax variant (A/B); WPS: min waves per SIMD
+__global__ __launch_bounds__(AT_THREADS, WPS) void flash_attn_kernel(const AttnParams p) {
     constexpr int DV = (DK + 1) / 2;            // 32-row tiles of O^T
     constexpr bool ONES = (DK & 1) != 0;        // d <= 16*DK < 32*DV: a spare V^T row exists -> row-sum of P by MFMA
     constexpr int KLD = 16 * DK + 8;            // K tile row stride (halfs)
@@ -62,24 +62,53 @@ __global__ __launch_bounds__(AT_THREADS) void flash_attn_kernel(const AttnParams
 
     uint4 rk[KIT], rv[VIT];
     const int dch = d >> 3;   // real 16-byte chunks per key row
+    // Loader state hoisted out of the tile loop: per-thread source pointers that advance by a constant per tile and
+    // the tile-independent part of each chunk's validity.  Only the ragged LAST tile re-checks keys against Lk
+    // (wave-uniform branch), so the steady state issues bare 16-byte loads.
+    const half_t* kp[KIT];
+    const half_t* vp[VIT];
+    bool kin[KIT], vin[VIT];
+    int krow[KIT], vcol[VIT];
+    bool vones[VIT];
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+        const int q = tid + i * AT_THREADS;
+        const int row = q / (2 * DK), cc = q - row * (2 * DK);
+        krow[i] = row;
+        kin[i] = q < KCH && cc < dch;
+        kp[i] = Kg + (long long)row * p.ldk + cc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < VIT; ++i) {
+        const int q = tid + i * AT_THREADS;
+        const int row = q / (KT_KEYS / 8), cc = q - row * (KT_KEYS / 8);
+        vcol[i] = cc * 8;
+        vin[i] = q < VCH && row < d;
+        vp[i] = Vg + (long long)row * p.ldvt + cc * 8;
+        // spare row 32*DV-1 := 1.0 (fp16 0x3C00): O^T row 32*DV-1 then accumulates sum_k P[k], the softmax
+        // denominator, on the matrix core instead of 16 VALU adds per tile
+        vones[i] = ONES && row == 32 * DV - 1;
+    }
+    auto fill = [&](int i) {   // what a V^T chunk holds when it is not loaded: the ones row, or zeros
+        const unsigned w = vones[i] ? 0x3C003C00u : 0u;
+        return make_uint4(w, w, w, w);
+    };
     auto prefetch = [&](int key0) {
+        if (key0 + KT_KEYS <= p.Lk) {          // full tile: no per-key checks
 #pragma unroll
-        for (int i = 0; i < KIT; ++i) {
-            const int q = tid + i * AT_THREADS;
-            const int row = q / (2 * DK), cc = q - row * (2 * DK);
-            const bool ok = q < KCH && cc < dch && key0 + row < p.Lk;
-            rk[i] = ok ? ld16(Kg + (long long)(key0 + row) * p.ldk + cc * 8) : zero16();
+            for (int i = 0; i < KIT; ++i) rk[i] = kin[i] ? ld16(kp[i]) : zero16();
+#pragma unroll
+            for (int i = 0; i < VIT; ++i) rv[i] = vin[i] ? ld16(vp[i]) : fill(i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < KIT; ++i) rk[i] = (kin[i] && key0 + krow[i] < p.Lk) ? ld16(kp[i]) : zero16();
+#pragma unroll
+            for (int i = 0; i < VIT; ++i) rv[i] = (vin[i] && key0 + vcol[i] < p.Lk) ? ld16(vp[i]) : fill(i);
         }
 #pragma unroll
-        for (int i = 0; i < VIT; ++i) {
-            const int q = tid + i * AT_THREADS;
-            const int row = q / (KT_KEYS / 8), cc = q - row * (KT_KEYS / 8);
-            const bool ok = q < VCH && row < d && key0 + cc * 8 < p.Lk;
-            // spare row 32*DV-1 := 1.0 (fp16 0x3C00): O^T row 32*DV-1 then accumulates sum_k P[k], the softmax
-            // denominator, on the matrix core instead of 16 VALU adds per tile
-            const uint4 fill = (ONES && row == 32 * DV - 1) ? make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u) : zero16();
-            rv[i] = ok ? ld16(Vg + (long long)row * p.ldvt + key0 + cc * 8) : fill;
-        }
+        for (int i = 0; i < KIT; ++i) kp[i] += (long long)KT_KEYS * p.ldk;
+#pragma unroll
+        for (int i = 0; i < VIT; ++i) vp[i] += KT_KEYS;
     };
     auto commit = [&]() {
 #pragma unroll
@@ -217,6 +246,14 @@ void launch_attn(const AttnParams& p, hipStream_t s) {
     static const int env_kt = getenv("LD_ATTN_KT") ? atoi(getenv("LD_ATTN_KT")) : 64;   // A/B knob; 64 measured best (profiles/r01_c)
     const int nblk = ((p.Lq + 127) / 128) * p.H * p.B;
     static const int env_smx = getenv("LD_ATTN_SMX") ? atoi(getenv("LD_ATTN_SMX")) : 1;
+    // min waves per SIMD handed to __launch_bounds__: with it hipcc keeps the MFMA accumulators in VGPRs (no v_accvgpr
+    // copies around the softmax) and fits 3-4 waves per SIMD for the small heads: +25 % at d=40 (profiles/README.md).
+    static const int env_wps = getenv("LD_ATTN_WPS") ? atoi(getenv("LD_ATTN_WPS")) : -1;   // -1 auto, 0 none
+    constexpr int AUTO_WPS = DK <= 5 ? 3 : 2;
+    if (env_wps != 0 && !(DK <= 5 && env_kt == 128) && env_smx != 0) {
+        hipLaunchKernelGGL((flash_attn_kernel<DK, 64, 1, AUTO_WPS>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
+        return;
+    }
     if (DK <= 5 && env_kt == 128)
         hipLaunchKernelGGL((flash_attn_kernel<DK, (DK <= 5 ? 128 : 64)>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
     else if (env_smx == 0)
