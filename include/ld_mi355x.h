@@ -104,7 +104,7 @@ int ld_vae_last_launches(const ld_vae* v);
 double ld_vae_last_flops(const ld_vae* v);
 
 /* ------------------------------------------------------------------ single operators (fp16 device tensors unless noted) */
-/* y[M][N] = act(alpha * x[M][K] · w[N][K]^T + bias[N]) + residual[M][N];  act: 0 none, 1 SiLU, 2 GEGLU (w, bias in
+/* y[M][N] = act(alpha * x[M][K] · w[N][K]^T + bias[N]) + residual[M][N];  act: 0 none, 1 SiLU, 3 quick-GELU, 2 GEGLU (w, bias in
  * checkpoint row order [value | gate]; y is [M][N/2]).  ws/ws_bytes: optional split-K scratch. */
 int ld_op_linear(const void* x, const void* w, const void* bias, const void* residual, void* y, int M, int N, int K,
                  float alpha, int act, void* ws, size_t ws_bytes, void* stream);
@@ -119,9 +119,10 @@ size_t ld_op_groupnorm_ws_bytes(int n, int hw);
 int ld_op_groupnorm(const void* x1, int c1, const void* x2, int c2, int n, int hw, const void* gamma, const void* beta,
                     float eps, int silu, void* y, void* ws, void* stream);
 int ld_op_layernorm(const void* x, const void* gamma, const void* beta, void* y, int rows, int c, float eps, void* stream);
-/* q [b][lq][heads*d], k [b][lk][heads*d], vt [b][heads*d][lk_pad] (V transposed, lk_pad = ldvt >= lk, multiple of 8) */
+/* q [b][lq][heads*d], k [b][lk][heads*d], vt [b][heads*d][lk_pad] (V transposed, lk_pad = ldvt >= lk, multiple of 8);
+ * causal != 0 masks keys after the query position (the CLIP text model's mask, LD.py:4440-4446) */
 int ld_op_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo, int b,
-                    int heads, int lq, int lk, int d, float scale, void* stream);
+                    int heads, int lq, int lk, int d, float scale, int causal, void* stream);
 int ld_op_softmax_rows(void* s, int rows, int cols, void* stream);
 int ld_op_timestep_embed(const float* sigma, const float* log_sigmas, int n_sigmas, int n, int dim, void* out_f16, float* t_out,
                          void* stream);

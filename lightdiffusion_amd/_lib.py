@@ -71,7 +71,7 @@ SIGNATURES = {
     "ld_op_groupnorm_ws_bytes": (_Z, [_I, _I]),
     "ld_op_groupnorm": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P]),
     "ld_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
-    "ld_op_attention": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "ld_op_attention": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "ld_op_softmax_rows": (_I, [_P, _I, _I, _P]),
     "ld_op_timestep_embed": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "ld_op_cfg_combine": (_I, [_P, _P, _F, _Z, _P]),

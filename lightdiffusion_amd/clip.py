@@ -160,6 +160,52 @@ class CLIPTextModel:
         return x, inter, pooled
 
 
+class CLIPTextModelHIP(CLIPTextModel):
+    """The same text transformer on the HIP kernels: LayerNorm, fused [q|k|v] projection, causal
+    flash attention, out-projection + residual epilogue, fc1 + quick-GELU epilogue, fc2 + residual epilogue — all through
+    the C ABI (`ops`), fp16 storage / fp32 accumulation.  Only the embedding gather (77 rows) and the final row pick for the
+    pooled output stay torch indexing.  The reference computes this model in fp32; the conditioning it feeds is cast to
+    fp16 by `apply_model` (LD.py:5846), so the tolerance here is the per-op fp16 one."""
+
+    def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], device="cuda:0"):
+        super().__init__(cfg, weights, device, weight_dtype=torch.float16)
+        P = "text_model.encoder.layers."
+        self.qkv = []
+        for i in range(cfg["num_hidden_layers"]):
+            p = f"{P}{i}.self_attn."
+            w = torch.cat([self.w[p + f"{t}_proj.weight"] for t in "qkv"]).contiguous()
+            b = torch.cat([self.w[p + f"{t}_proj.bias"] for t in "qkv"]).contiguous()
+            self.qkv.append((w, b))
+
+    @torch.no_grad()
+    def __call__(self, tokens: torch.Tensor, intermediate_output: Optional[int] = None):
+        from . import ops
+        P = "text_model."
+        h, heads, nl = self.cfg["hidden_size"], self.cfg["num_attention_heads"], self.cfg["num_hidden_layers"]
+        tokens = tokens.to(self.device)
+        x = (self.w[P + "embeddings.token_embedding.weight"][tokens].float() +
+             self.w[P + "embeddings.position_embedding.weight"].float()).half().contiguous()        # [B, 77, h]
+        B, L = x.shape[:2]
+        stop = None if intermediate_output is None else (nl + intermediate_output if intermediate_output < 0 else intermediate_output)
+        inter = None
+        ln = lambda t, p: ops.layer_norm(t, self.w[p + ".weight"], self.w[p + ".bias"], 1e-5)
+        for i in range(nl):
+            p = f"{P}encoder.layers.{i}"
+            qkv = ops.linear(ln(x, p + ".layer_norm1"), *self.qkv[i])                                 # [B, L, 3h]
+            q, k, v = (qkv[..., j * h:(j + 1) * h].contiguous() for j in range(3))
+            a = ops.attention(q, k, v, heads, causal=True)
+            x = ops.linear(a, self.w[p + ".self_attn.out_proj.weight"], self.w[p + ".self_attn.out_proj.bias"], residual=x)
+            m = ops.linear(ln(x, p + ".layer_norm2"), self.w[p + ".mlp.fc1.weight"], self.w[p + ".mlp.fc1.bias"], act="quick_gelu")
+            x = ops.linear(m, self.w[p + ".mlp.fc2.weight"], self.w[p + ".mlp.fc2.bias"], residual=x)
+            if i == stop:
+                inter = x.clone()
+        x = ln(x, P + "final_layer_norm")
+        if inter is not None:
+            inter = ln(inter, P + "final_layer_norm")
+        pooled = x[torch.arange(B, device=self.device), tokens.to(torch.int).argmax(dim=-1)]
+        return x.float(), None if inter is None else inter.float(), pooled.float()
+
+
 class CLIP:
     """The object `CLIPTextEncode.encode(clip, text)` drives (LD.py:6222-6272)."""
 

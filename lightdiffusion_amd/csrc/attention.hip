@@ -155,6 +155,14 @@ __global__ __launch_bounds__(AT_THREADS, WPS) void flash_attn_kernel(const AttnP
                 const half8 kf = as_half8(ld16(Ks + (sub * 32 + prow) * KLD + 16 * ks + 8 * hh));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
             }
+            if (p.causal) {                        // causal: key index must not exceed the query index
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    const int key = (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
+                    if (key0 + sub * 32 + key > qrow) s[e] = -INFINITY;
+                }
+            }
             if (key0 + sub * 32 + 32 > p.Lk) {   // ragged last tile: mask keys >= Lk
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {

@@ -102,13 +102,13 @@ int ld_op_layernorm(const void* x, const void* gamma, const void* beta, void* y,
 }
 
 int ld_op_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo, int b, int heads,
-                    int lq, int lk, int d, float scale, void* stream) {
+                    int lq, int lk, int d, float scale, int causal, void* stream) {
     AttnParams a;
     a.Q = (const half_t*)q; a.ldq = ldq; a.sQ = (long long)lq * ldq;
     a.K = (const half_t*)k; a.ldk = ldk; a.sK = (long long)lk * ldk;
     a.Vt = (const half_t*)vt; a.ldvt = ldvt; a.sV = (long long)heads * d * ldvt;
     a.O = (half_t*)o; a.ldo = ldo; a.sO = (long long)lq * ldo;
-    a.B = b; a.H = heads; a.Lq = lq; a.Lk = lk; a.d = d; a.scale = scale;
+    a.B = b; a.H = heads; a.Lq = lq; a.Lk = lk; a.d = d; a.scale = scale; a.causal = causal;
     return attention_launch(a, (hipStream_t)stream);
 }
 

@@ -61,6 +61,9 @@ __device__ __forceinline__ float gelu_f(float x) {
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// quick_gelu of the CLIP MLP: a * sigmoid(1.702 a)  (ACTIVATIONS, LD.py:4296-4299)
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -32,7 +32,7 @@ struct GemmParams {
     int rows_per_vec = 1, ldrv = 0;
     const half_t* R = nullptr;
     int ldr = 0;
-    int act = 0;                 // 0 none, 1 SiLU, 2 GEGLU (weight rows tile-interleaved [BN/2 value | BN/2 gate], out width N/2)
+    int act = 0;                 // 0 none, 1 SiLU, 3 quick-GELU, 2 GEGLU (weight rows tile-interleaved [BN/2 value | BN/2 gate], out width N/2)
     half_t* C = nullptr;
     int ldc = 0;
     // ---- tiling controls (0 = auto)

@@ -39,6 +39,9 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int 
     if (p.act == 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
+    } else if (p.act == 3) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = quick_gelu_f(v[j]);
     }
     if (p.R != nullptr) {
         float r[8];
@@ -121,6 +124,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
                     for (int j = 0; j < 8; ++j) {
                         float t = v[j] + b[j] + bm + e[j];
                         if (p.act == 1) t = silu_f(t);
+                        else if (p.act == 3) t = quick_gelu_f(t);
                         v[j] = t + r[j];
                     }
                     st16(p.C + (long long)z * p.sC + (long long)m * p.ldc + n, pack8(v));

@@ -29,6 +29,7 @@ struct AttnParams {
     long long sQ = 0, sK = 0, sV = 0, sO = 0;
     int B = 0, H = 0, Lq = 0, Lk = 0, d = 0;
     float scale = 1.0f;
+    int causal = 0;              // key index <= query index only (CLIP text model, LD.py:4440-4446)
 };
 int attention_launch(const AttnParams& p, hipStream_t stream);
 

@@ -19,7 +19,7 @@ import torch
 
 from . import sampling
 from . import weights as W
-from .clip import CLIP, CLIPTextModel, PromptTokenizer
+from .clip import CLIP, CLIPTextModel, CLIPTextModelHIP, PromptTokenizer
 from .sampling import LATENT_SCALE, common_ksampler
 from .unet import MI355XUNet, MI355XVAE
 
@@ -172,7 +172,7 @@ def load_synthetic(device="cuda:0", max_batch: int = 1, max_hw=(64, 64), tiny: b
     unet = MI355XUNet(ucfg, gen, device=device, max_batch=2 * max_batch, max_hw=max_hw)
     vae = MI355XVAE(vcfg, gen, device=device, max_batch=max_batch, max_hw=max_hw, with_encoder=True)
     tok = PromptTokenizer.from_pretrained(tokenizer_dir) if tokenizer_dir else None
-    clip = CLIP(CLIPTextModel(ccfg, W.synth_state_dict(W.clip_param_shapes(ccfg), seed), device=device), tok)
+    clip = CLIP(CLIPTextModelHIP(ccfg, W.synth_state_dict(W.clip_param_shapes(ccfg), seed), device=device), tok)
     return _attach(unet, device), clip, vae
 
 
@@ -196,7 +196,7 @@ class CheckpointLoaderSimple:
         vae = MI355XVAE(vcfg, sd, device=self.device, max_batch=self.max_batch, max_hw=self.max_hw, with_encoder=has_enc)
         csd = CK.clip_state_dict(sd)
         tok = PromptTokenizer.from_pretrained(self.tokenizer_dir) if self.tokenizer_dir else None
-        clip = CLIP(CLIPTextModel(CK.detect_clip_config(csd, self.clip_heads), csd, device=self.device), tok)
+        clip = CLIP(CLIPTextModelHIP(CK.detect_clip_config(csd, self.clip_heads), csd, device=self.device), tok)
         return _attach(unet, self.device), clip, vae
 
 

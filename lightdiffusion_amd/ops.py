@@ -34,7 +34,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
            act: str = "none", alpha: float = 1.0) -> torch.Tensor:
     """y = act(alpha * x @ weight.T + bias) + residual.  x [..., K] fp16, weight [N, K] fp16 (nn.Linear layout).
     act='geglu': weight/bias rows are [value | gate] as in the checkpoint (LD.py:4508-4515); y has N/2 columns."""
-    code = {"none": 0, "silu": 1, "geglu": 2}[act]
+    code = {"none": 0, "silu": 1, "geglu": 2, "quick_gelu": 3}[act]
     K = x.shape[-1]
     N = weight.shape[0]
     M = x.numel() // K
@@ -96,7 +96,7 @@ def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: fl
     return y
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tensor:
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, causal: bool = False) -> torch.Tensor:
     """optimized_attention(q, k, v, heads) of LD.py:3966-3978: q [b,Lq,heads*d], k/v [b,Lk,heads*d] -> [b,Lq,heads*d].
     (The executor never materialises V^T like this — its projection GEMM writes V^T directly.)"""
     b, lq, c = q.shape
@@ -106,7 +106,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> 
     vt = torch.zeros(b, c, lkp, dtype=torch.float16, device=q.device)
     vt[:, :, :lk] = v.transpose(1, 2)
     o = torch.empty_like(q)
-    check(lib().ld_op_attention(_p(q), c, _p(k.contiguous()), c, _p(vt), lkp, _p(o), c, b, heads, lq, lk, d, 1.0 / math.sqrt(d), _stream()),
+    check(lib().ld_op_attention(_p(q), c, _p(k.contiguous()), c, _p(vt), lkp, _p(o), c, b, heads, lq, lk, d, 1.0 / math.sqrt(d), int(causal), _stream()),
           "ld_op_attention")
     return o
 

@@ -111,3 +111,22 @@ def test_vae_encode_golden(tag, hw):
     assert z.device.type == "cpu" and rel_l2(z, g["z_seed58"]) < 5e-3
     img = v.decode(z)                                   # round trip through the decoder still works on the same handle
     assert img.shape == g["pixels"].shape and torch.isfinite(img).all()
+
+
+def test_clip_text_model_on_hip_kernels():
+    """the CLIP-L text transformer through the C ABI kernels vs the reference's CLIPTextModel golden
+    (tiny config) and vs the pinned oracle at full CLIP-L size."""
+    from lightdiffusion_amd.clip import CLIP, CLIPTextModelHIP
+    g = load_golden("clip_tiny")
+    cfg = W.tiny_clip_config()
+    tm = CLIPTextModelHIP(cfg, W.synth_state_dict(W.clip_param_shapes(cfg)), device=DEV)
+    last, inter, pooled = tm(g["tokens"], intermediate_output=-2)
+    assert rel_l2(last.cpu(), g["last"]) < 5e-3 and rel_l2(inter.cpu(), g["inter_m2"]) < 5e-3 and rel_l2(pooled.cpu(), g["pooled"]) < 5e-3
+    cond = CLIP(tm, None, layer_idx=-2).encode_from_tokens([[(t, 1.0) for t in g["tokens"][0].tolist()]])
+    assert cond.shape == (1, 77, cfg["hidden_size"]) and cond.device.type == "cpu"
+    cfg = W.sd15_clip_config()
+    sd = W.synth_state_dict(W.clip_param_shapes(cfg))
+    toks = g["tokens"][:1]
+    ref = O.clip_text_model(sd, cfg, toks, layer_idx=-2)
+    out = CLIPTextModelHIP(cfg, sd, device=DEV)(toks, intermediate_output=-2)[1].cpu()
+    assert rel_l2(out, ref) < 5e-3

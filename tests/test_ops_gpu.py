@@ -205,3 +205,21 @@ def test_sampler_elementwise(ops):
     assert torch.allclose(out, u + (c - u) * 7.5, atol=1e-5)
     xx = ops.axpby_(x.to(DEV).clone(), 0.5, y.to(DEV), -2.0, z.to(DEV), 0.25).cpu()
     assert torch.allclose(xx, 0.5 * x - 2.0 * y + 0.25 * z, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,heads,l,d", [(2, 12, 77, 64), (1, 4, 77, 16), (2, 8, 200, 40)])
+def test_causal_attention(ops, b, heads, l, d):
+    c = heads * d
+    q, k, v = r16((b, l, c), 71), r16((b, l, c), 72), r16((b, l, c), 73)
+    qq, kk, vv = (t.float().view(b, l, heads, d).transpose(1, 2) for t in (q, k, v))
+    mask = torch.full((l, l), float("-inf")).triu_(1)
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) / math.sqrt(d) + mask, -1) @ vv).transpose(1, 2).reshape(b, l, c)
+    y = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads, causal=True)
+    assert rel_l2(y.float().cpu(), ref) < TOL
+
+
+def test_linear_quick_gelu(ops):
+    x, w, b = r16((154, 768), 74), r16((3072, 768), 75, 1 / math.sqrt(768)), r16((3072,), 76, 0.1)
+    ref = F.linear(x.float(), w.float(), b.float())
+    ref = ref * torch.sigmoid(1.702 * ref)
+    assert rel_l2(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act="quick_gelu").float().cpu(), ref) < TOL

@@ -8,7 +8,7 @@ def case(b, heads, l, lk, d, reps=10):
     lkp = (lk + 7) // 8 * 8
     vt = torch.randn(b, c, lkp, device=DEV, dtype=torch.float16); o = torch.empty_like(q)
     s = torch.cuda.current_stream().cuda_stream
-    run = lambda: check(lib().ld_op_attention(q.data_ptr(), c, k.data_ptr(), c, vt.data_ptr(), lkp, o.data_ptr(), c, b, heads, l, lk, d, 1 / math.sqrt(d), s), "attn")
+    run = lambda: check(lib().ld_op_attention(q.data_ptr(), c, k.data_ptr(), c, vt.data_ptr(), lkp, o.data_ptr(), c, b, heads, l, lk, d, 1 / math.sqrt(d), 0, s), "attn")
     run(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
