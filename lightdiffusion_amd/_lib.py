@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libld_mi355x.so")
+LIB_PATH = os.environ.get("LD_MI355X_LIB") or os.path.join(_HERE, "libld_mi355x.so")   # env: debug builds only
 
 OK, ERR_ARG, ERR_SHAPE, ERR_HIP, ERR_STATE = 0, 1, 2, 3, 4
 F16, F32 = 0, 1

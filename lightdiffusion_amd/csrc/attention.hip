@@ -15,6 +15,9 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#ifndef LD_ATT_DBG
+#define LD_ATT_DBG 0
+#endif
 
 namespace {
 
@@ -140,10 +143,17 @@ __global__ __launch_bounds__(AT_THREADS, WPS) void flash_attn_kernel(const AttnP
     prefetch(0);
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KT_KEYS;
+#if LD_ATT_DBG == 2
+        if (t == 0) {
+#endif
         __syncthreads();   // every wave is done reading the previous tile (and, for t = 0, the zero fill landed)
         commit();
         __syncthreads();
+#if LD_ATT_DBG == 2
+        }
+#else
         if (t + 1 < ntiles) prefetch(key0 + KT_KEYS);
+#endif
 #pragma unroll
         for (int sub = 0; sub < KT_KEYS / 32; ++sub) {
             if (key0 + sub * 32 >= p.Lk) break;   // wave-uniform: nothing valid in this half tile
@@ -190,8 +200,12 @@ __global__ __launch_bounds__(AT_THREADS, WPS) void flash_attn_kernel(const AttnP
             half8 pf[2];
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
+#if LD_ATT_DBG == 1
+                const float p0 = s[e] * c2 - mc, p1 = s[e + 1] * c2 - mc;
+#else
                 const float p0 = __builtin_amdgcn_exp2f(s[e] * c2 - mc);       // raw v_exp_f32: argument <= 0
                 const float p1 = __builtin_amdgcn_exp2f(s[e + 1] * c2 - mc);
+#endif
                 if (!ONES) psum += p0 + p1;
                 // one v_cvt_pkrtz_f16_f32 per pair (instead of 2 cvt + 1 pack).  Round-toward-zero biases P by < 2^-10
                 // relative; numerator and (MFMA row-sum) denominator are built from the same rounded P, so it cancels.
@@ -215,9 +229,9 @@ __global__ __launch_bounds__(AT_THREADS, WPS) void flash_attn_kernel(const AttnP
             l_run += psum;
             m_run = m_new;
 #pragma unroll
-            for (int tt = 0; tt < DV; ++tt)
+            for (int tt = 0; tt < (LD_ATT_DBG == 3 ? 1 : DV); ++tt)
 #pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
+                for (int k2 = 0; k2 < (LD_ATT_DBG == 3 ? 1 : 2); ++k2) {
                     const half8 vf = as_half8(ld16(Vs + (tt * 32 + r) * VLD + sub * 32 + 16 * k2 + 8 * hh));
                     o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[k2], o[tt], 0, 0, 0);
                 }
@@ -249,6 +263,267 @@ __global__ __launch_bounds__(AT_THREADS, WPS) void flash_attn_kernel(const AttnP
     }
 }
 
+
+// =====================================================================================================================
+// v2: same math and register layout as above, different tile pipeline.  K / V^T tiles go global -> LDS by LDS-DMA
+// (no register staging, no commit stores) into a DOUBLE-buffered pair, so a tile costs one s_barrier instead of two and
+// its loads have a whole tile of MFMA + softmax time to land.  Ablation on the v1 kernel (profiles/README.md): removing
+// the per-tile commit + 2 barriers alone was worth 25 % (d=40) to 36 % (d=80).
+//  * K tile: dense rows of d halfs (d/8 16-byte chunks); chunk c of row `row` sits at physical chunk c ^ swz(row), with
+//    the XOR width chosen from the row stride so that 8 consecutive rows land in 8 distinct 16-byte slots of a 128-byte
+//    bank line (d=40: stride 80 B needs none; d=80: 1 bit; d=160: 2 bits).  The DMA writes lane-linear, so the swizzle
+//    is applied to the SOURCE address of each lane and to the fragment read alike.
+//  * V^T tile: 32*DV rows of 64 keys (8 chunks), chunk ^= row & 7.  Rows >= d are sourced from a zero page (and the
+//    spare "ones" row from a page of fp16 1.0) every tile: the tile is always whole instructions, nothing to pre-fill.
+//  * a d that is an odd multiple of 8 leaves one pad chunk in the last QK^T k-step; the matching Q fragment is zero and
+//    the pad chunk reads the next row's first chunk (or the zero-filled slack after the last row): 0 * finite = 0.
+// =====================================================================================================================
+__device__ uint4 g_att_zero[8];                                                     // 128 zero bytes
+__device__ uint4 g_att_ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};   // 8 x fp16 1.0
+
+template <int DK, bool MASKED, int NW, int WPS>   // NW waves = 32*NW queries per workgroup share each K / V^T tile
+__global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnParams p) {
+    constexpr int DV = (DK + 1) / 2;
+    constexpr bool ONES = (DK & 1) != 0;
+    constexpr int KT = 64;
+    constexpr int NT2 = 64 * NW;
+    constexpr int LIT = (DV * 256 + NT2 - 1) / NT2;   // loader wave-instructions per tile
+    constexpr int TILE_CH = LIT * NT2;             // 16-byte chunks per K tile and per V^T tile (whole wave-instructions)
+    constexpr int BUF_H = 2 * TILE_CH * 8;         // halfs per buffer (K tile then V^T tile)
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * BUF_H];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int qblocks = (p.Lq + 32 * NW - 1) / (32 * NW);
+    const int nblk = qblocks * p.H * p.B;
+    int bid = xcd_remap(blockIdx.x, nblk);
+    const int qb = bid % qblocks;
+    bid /= qblocks;
+    const int head = bid % p.H, b = bid / p.H;
+    const int d = p.d, dch = d >> 3;
+
+    const half_t* Qg = p.Q + (long long)b * p.sQ + head * d;
+    const half_t* Kg = p.K + (long long)b * p.sK + head * d;
+    const half_t* Vg = p.Vt + (long long)b * p.sV + (long long)head * d * p.ldvt;
+    const half_t* zp = reinterpret_cast<const half_t*>(g_att_zero);
+    const half_t* op = reinterpret_cast<const half_t*>(&g_att_ones);
+
+    const int qrow = qb * (32 * NW) + wid * 32 + r;
+    // Q is folded with scale*log2(e) once, so QK^T comes out of the matrix core already in the exp2 domain
+    // (one fp16 rounding of q*c2: the same size of error the fp16 P tile carries anyway).
+    const float c2 = p.scale * 1.44269504088896340736f;
+    half8 qf[DK];
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks) {
+        const int c = 16 * ks + 8 * hh;
+        float qv[8];
+        unpack8((qrow < p.Lq && c < d) ? ld16(Qg + (long long)qrow * p.ldq + c) : zero16(), qv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] *= c2;
+        qf[ks] = as_half8(pack8(qv));
+    }
+
+    // K-row swizzle: XOR the low tz bits of the chunk index with row bits [3-tz, 3)
+    int tz = 0;
+    while (tz < 3 && !((dch >> tz) & 1)) ++tz;
+    const int sw_mask = (1 << tz) - 1, sw_shift = 3 - tz;
+
+    // ---- loader state (one entry per wave-instruction)
+    const half_t* kp[LIT];
+    const half_t* vp[LIT];
+    bool kval[LIT], vdat[LIT];
+    int krow[LIT], vkey[LIT];
+#pragma unroll
+    for (int i = 0; i < LIT; ++i) {
+        const int q = tid + i * NT2;
+        const int row = q / dch, cph = q - row * dch;
+        krow[i] = row;
+        kval[i] = row < KT;
+        kp[i] = kval[i] ? Kg + (long long)row * p.ldk + ((cph ^ ((row >> sw_shift) & sw_mask)) << 3) : zp;
+        const int vr = q >> 3, vc = (q & 7) ^ (vr & 7);
+        vkey[i] = vc << 3;
+        vdat[i] = vr < d;
+        vp[i] = vdat[i] ? Vg + (long long)vr * p.ldvt + (vc << 3) : ((ONES && vr == 32 * DV - 1) ? op : zp);
+    }
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    auto issue = [&](int key0, int buf) {
+        const unsigned Kb = smem_base + (unsigned)(buf * BUF_H) * 2u + (unsigned)(wid * 64) * 16u;
+        const unsigned Vb = Kb + (unsigned)TILE_CH * 16u;
+        if (!MASKED || key0 + KT <= p.Lk) {
+#pragma unroll
+            for (int i = 0; i < LIT; ++i) glds16(kp[i], Kb + (unsigned)(i * NT2) * 16u);
+#pragma unroll
+            for (int i = 0; i < LIT; ++i) glds16(vp[i], Vb + (unsigned)(i * NT2) * 16u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < LIT; ++i) glds16((kval[i] && key0 + krow[i] >= p.Lk) ? zp : kp[i], Kb + (unsigned)(i * NT2) * 16u);
+#pragma unroll
+            for (int i = 0; i < LIT; ++i) glds16((vdat[i] && key0 + vkey[i] >= p.Lk) ? zp : vp[i], Vb + (unsigned)(i * NT2) * 16u);
+        }
+#pragma unroll
+        for (int i = 0; i < LIT; ++i) kp[i] += kval[i] ? (long long)KT * p.ldk : 0;
+#pragma unroll
+        for (int i = 0; i < LIT; ++i) vp[i] += vdat[i] ? KT : 0;
+    };
+
+    // ---- fragment read offsets (halfs, relative to the K tile / V^T tile of a buffer)
+    const int prow = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);   // bit-2 <-> bit-3 row permutation (see header)
+    const int ksw = (prow >> sw_shift) & sw_mask;                   // same for row + 32: only row bits < 3 enter
+    int koff[DK];
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks) koff[ks] = (prow * dch + ((2 * ks + hh) ^ ksw)) << 3;
+    int voff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) voff[c] = TILE_CH * 8 + ((r * 8 + ((2 * c + hh) ^ (r & 7))) << 3);   // c = 2*sub + k2
+
+    f32x16 o[DV];
+#pragma unroll
+    for (int t = 0; t < DV; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    // Softmax reference ("lazy max"): scores leave the QK^T MFMA as s - m_ref because -m_ref is its C operand, so the
+    // steady state has no per-element subtract/scale at all.  m_ref moves only when a tile's maximum exceeds it by more
+    // than TAU (P <= 2^TAU stays well inside fp16, O / l accumulate in fp32) — then the tile is shifted and O, l rescaled;
+    // numerator and denominator always share one reference, so the result is the exact softmax, not a thresholded one.
+    constexpr float TAU = 8.0f;
+    float m_ref = 0.f, l_run = 0.f;
+    f32x16 negm;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) negm[e] = 0.f;
+
+    const int ntiles = (p.Lk + KT - 1) / KT;
+    // Retire the Q loads HERE with the builtin (which hipcc's waitcnt pass models): otherwise the pass parks a vmcnt(0)
+    // for them at the first MFMA inside the loop, where it also drains the next tile's in-flight LDS-DMA every iteration.
+    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0), expcnt/lgkmcnt untouched
+    issue(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * KT;
+        wait_vmcnt<0>();                   // this wave's share of tile t has landed ...
+        __builtin_amdgcn_s_barrier();      // ... everyone's has, and nobody still reads tile t-1's buffer
+        if (t + 1 < ntiles) issue(key0 + KT, (t + 1) & 1);
+        const half_t* T = smem + (t & 1) * BUF_H;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (MASKED && key0 + sub * 32 >= p.Lk) break;   // wave-uniform: nothing valid in this half tile
+            f32x16 s;
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) {
+#if LD_ATT_DBG == 4
+                const half8 kf = as_half8(ld16(T + sub * 32 * d + koff[0]));
+#else
+                const half8 kf = as_half8(ld16(T + sub * 32 * d + koff[ks]));
+#endif
+                // first k-step in asm: D (early-clobber) != C pins the three-address form, so -m_ref is read in place as C;
+                // through the builtin hipcc ties D to C and copies the 16 reference registers every other subtile.
+                // (Hazards: the next reader of s is the following MFMA with C == D — no wait states; the VALU readers
+                // come after builtin MFMAs, which the compiler's hazard recogniser spaces as usual.)
+                // DK == 1 has no builtin MFMA behind the asm one, so nothing would space the VALU readers: builtin there.
+                if (ks == 0 && DK == 1) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], negm, 0, 0, 0);
+                else if (ks == 0) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s) : "v"(kf), "v"(qf[0]), "v"(negm));
+                else s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+            }
+            if (MASKED) {
+                if (p.causal) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int i = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        const int key = (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
+                        if (key0 + sub * 32 + key > qrow) s[e] = -INFINITY;
+                    }
+                }
+                if (key0 + sub * 32 + 32 > p.Lk) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int i = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        const int key = (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
+                        if (key0 + sub * 32 + key >= p.Lk) s[e] = -INFINITY;
+                    }
+                }
+            }
+            // Softmax runs at raised wave priority.  Measured on this chip (tools/micro/coexec.hip): a VALU stream and an MFMA
+            // stream of two waves on one SIMD take the SUM of their times at equal priority (the MFMA wave holds the vector
+            // issue port while the matrix pipe is busy) and the MAX when the VALU wave has priority 1 — so the wave that is in
+            // its exp/max phase goes first and the other resident waves' MFMAs fill the matrix pipe underneath it.
+            __builtin_amdgcn_s_setprio(1);
+            // 16 -> 1 by v_max3_f32 (this file is built with -fno-honor-nans: otherwise fmaxf() adds a NaN-quieting
+            // v_max x,x per MFMA output), then the other half-wave (the other 16 keys of the same query) by one
+            // v_permlane32_swap — no LDS round trip
+            float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+            for (int e = 3; e + 1 < 16; e += 2) mx = fmaxf(fmaxf(mx, s[e]), s[e + 1]);
+            mx = fmaxf(mx, s[15]);
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const bool first = (t == 0 && sub == 0);   // the reference starts at 0: the first tile moves it to its own maximum
+            if (first || __any(mx > TAU)) {
+                const float delta = first ? mx : (mx > TAU ? mx : 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_ref += delta;
+                l_run *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] -= delta;
+                {   // in-place (tied asm operand): keeps -m_ref in ONE register tile across both arms of this branch, otherwise
+                    // the allocator gives each arm its own tile and copies 16 registers on the common path
+                    const float nm = -m_ref;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) asm volatile("v_mov_b32 %0, %1" : "+v"(negm[e]) : "v"(nm));
+                }
+#pragma unroll
+                for (int tt = 0; tt < DV; ++tt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[tt][e] *= alpha;
+            }
+            float psum = 0.f;
+            half8 pf[2];
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[e]);
+                const float p1 = __builtin_amdgcn_exp2f(s[e + 1]);
+                if (!ONES) psum += p0 + p1;
+                const half2v h2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+                pf[e >> 3][e & 7] = h2[0];
+                pf[e >> 3][(e & 7) + 1] = h2[1];
+            }
+            l_run += psum;
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int tt = 0; tt < DV; ++tt)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+#if LD_ATT_DBG == 4
+                    const half8 vf = as_half8(ld16(T + voff[2 * sub]));
+#else
+                    const half8 vf = as_half8(ld16(T + tt * 32 * 64 + voff[2 * sub + k2]));
+#endif
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[k2], o[tt], 0, 0, 0);
+                }
+        }
+    }
+
+    float l_tot;
+    if (ONES) l_tot = __shfl(o[DV - 1][15], 32 + r, 64);
+    else l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < p.Lq) {
+        half_t* Og = p.O + (long long)b * p.sO + (long long)qrow * p.ldo + head * d;
+#pragma unroll
+        for (int tt = 0; tt < DV; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = tt * 32 + 8 * g + 4 * hh;
+                if (dd < d) {
+                    half4 h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[tt][4 * g + e] * inv);
+                    *reinterpret_cast<half4*>(Og + dd) = h;
+                }
+            }
+    }
+}
+
 template <int DK>
 void launch_attn(const AttnParams& p, hipStream_t s) {
     static const int env_kt = getenv("LD_ATTN_KT") ? atoi(getenv("LD_ATTN_KT")) : 64;   // A/B knob; 64 measured best (profiles/r01_c)
@@ -258,6 +533,25 @@ void launch_attn(const AttnParams& p, hipStream_t s) {
     // copies around the softmax) and fits 3-4 waves per SIMD for the small heads: +25 % at d=40 (profiles/README.md).
     static const int env_wps = getenv("LD_ATTN_WPS") ? atoi(getenv("LD_ATTN_WPS")) : -1;   // -1 auto, 0 none
     constexpr int AUTO_WPS = DK <= 5 ? 3 : 2;
+    static const bool env_v1 = getenv("LD_ATTN_V1") != nullptr;   // A/B knob: the register-staged single-buffer kernel
+    if (!env_v1) {
+        // 8-wave workgroups (256 queries share a K / V^T tile: half the LDS-DMA and barrier work per query) once there
+        // are enough 256-query blocks to fill the chip at the same waves/SIMD; 4-wave workgroups otherwise.
+        static const int env_nw = getenv("LD_ATTN_NW") ? atoi(getenv("LD_ATTN_NW")) : 0;
+        const bool masked = p.causal || (p.Lk % 64) != 0;
+        const long long nblk8 = (long long)((p.Lq + 255) / 256) * p.H * p.B;
+        // measured (tools/attn_micro.py): d=40 L=4096 -1.6 %, L=16384 -5 %; d=80 L=1024 +1 % (142 VGPRs: one workgroup per CU)
+        const bool big = env_nw ? env_nw == 8 : (DK <= 4 && p.Lq >= 2048 && nblk8 >= 512);
+        if (big) {
+            constexpr int W8 = DK <= 4 ? 4 : 2;   // waves per SIMD the register budget is cut for (two or one workgroup per CU)
+            if (masked) hipLaunchKernelGGL((flash_attn2_kernel<DK, true, 8, W8>), dim3((unsigned)nblk8), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL((flash_attn2_kernel<DK, false, 8, W8>), dim3((unsigned)nblk8), dim3(512), 0, s, p);
+        } else {
+            if (masked) hipLaunchKernelGGL((flash_attn2_kernel<DK, true, 4, AUTO_WPS>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
+            else hipLaunchKernelGGL((flash_attn2_kernel<DK, false, 4, AUTO_WPS>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
+        }
+        return;
+    }
     if (env_wps != 0 && !(DK <= 5 && env_kt == 128) && env_smx != 0) {
         hipLaunchKernelGGL((flash_attn_kernel<DK, 64, 1, AUTO_WPS>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
         return;

@@ -82,6 +82,32 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
 }
 
+// One LDS-DMA wave-instruction: lane l copies 16 bytes from its own global address to LDS byte (lds_base + 16*l).
+// Issued through inline asm on purpose: hipcc's waitcnt pass does not see it, so it does not force vmcnt(0) before the
+// fragment reads of OTHER ring stages (with the builtin it does, draining the ring every K-step).  The counted
+// s_waitcnt vmcnt(N) + s_barrier in the loop are the only ordering (cdna guide §5.7: M0 is set and restored inside the
+// same statement; lds_base must be wave-uniform).
+__device__ __forceinline__ void glds16(const half_t* src, unsigned lds_base) {
+    // M0 is written and consumed inside the statement; nothing else in these kernels reads M0 (gfx9+ DS instructions do
+    // not), so it is not restored — two scalar instructions less per DMA in an issue-bound loop.
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, off"
+        :
+        : "v"(src), "s"(lds_base)
+        : "memory");
+}
+
+__device__ __forceinline__ unsigned lds_addr(const half_t* p) {
+    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 #define HIP_CHECK_RET(expr)                      \
     do {                                         \
         hipError_t _e = (expr);                  \

@@ -11,6 +11,9 @@
 #include <cstdlib>
 
 #include "gemm.h"
+#ifndef LD_DBG
+#define LD_DBG 0
+#endif
 
 namespace {
 
@@ -342,32 +345,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
 __device__ uint4 g_zero_page[8];   // 128 zero bytes: the source of padded / out-of-range chunks
 
 __device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
-
-// One LDS-DMA wave-instruction: lane l copies 16 bytes from its own global address to LDS byte (lds_base + 16*l).
-// Issued through inline asm on purpose: hipcc's waitcnt pass does not see it, so it does not force vmcnt(0) before the
-// fragment reads of OTHER ring stages (with the builtin it does, draining the ring every K-step).  The counted
-// s_waitcnt vmcnt(N) + s_barrier in the loop are the only ordering (cdna guide §5.7: M0 is set and restored inside the
-// same statement; lds_base must be wave-uniform).
-__device__ __forceinline__ void glds16(const half_t* src, unsigned lds_base) {
-    // M0 is written and consumed inside the statement; nothing else in these kernels reads M0 (gfx9+ DS instructions do
-    // not), so it is not restored — two scalar instructions less per DMA in an issue-bound loop.
-    asm volatile(
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %0, off"
-        :
-        : "v"(src), "s"(lds_base)
-        : "memory");
-}
-
-__device__ __forceinline__ unsigned lds_addr(const half_t* p) {
-    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p;
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GemmParams p) {
@@ -834,16 +811,29 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
     half8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     auto read_frags = [&](int stg, int kk, half8 (&fa)[TM], half8 (&fb)[TN]) {
         const half_t* S = smem + stg * STAGE;
+#if LD_DBG == 1 || LD_DBG == 3
+        if (kk == 0 && stg == 0)
+#endif
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[j] = as_half8(ld16(S + BM * BK3 + b_row[j] * BK3 + (((kk * 4 + fq) ^ (b_row[j] & 7)) << 3)));
+#if LD_DBG == 3
+        if (kk == 0 && stg == 0)
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[i] = as_half8(ld16(S + a_row[i] * BK3 + (((kk * 4 + fq) ^ (a_row[i] & 7)) << 3)));
     };
     auto mma = [&](const half8 (&fa)[TM], const half8 (&fb)[TN]) {
+#if LD_DBG == 2
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[i % TN], fa[i], acc[i][0], 0, 0, 0);
+#pragma unroll
+        for (int j = 1; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[0], acc[0][j], 0, 0, 0);
+#else
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+#endif
     };
 
     wait_vmcnt<LPT * (PF - 1)>();                    // slab kt_begin landed

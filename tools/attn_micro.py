@@ -16,4 +16,7 @@ def case(b, heads, l, lk, d, reps=10):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     print(f"attn b={b} h={heads} L={l} Lk={lk} d={d}: {ms*1e3:8.1f} us  {4.0*b*heads*l*lk*d/ms/1e9:7.1f} TF/s", flush=True)
-case(16, 8, 4096, 4096, 40); case(16, 8, 1024, 1024, 80); case(16, 8, 256, 256, 160); case(16, 8, 4096, 77, 40); case(8, 8, 16384, 16384, 40, 3)
+if len(sys.argv) > 1 and sys.argv[1] == 'quick':
+    case(16, 8, 4096, 4096, 40); case(16, 8, 1024, 1024, 80)
+else:
+    case(16, 8, 4096, 4096, 40); case(16, 8, 1024, 1024, 80); case(16, 8, 256, 256, 160); case(16, 8, 4096, 77, 40); case(8, 8, 16384, 16384, 40, 3)
