@@ -343,6 +343,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
 // which makes every ds_read_b128 lane group of the 16x16x32 fragment reads hit 16 distinct 16-byte slots.
 // =====================================================================================================================
 __device__ uint4 g_zero_page[8];   // 128 zero bytes: the source of padded / out-of-range chunks
+__device__ uint4 g_zero_row[4096];  // 64 KB of zeros: a whole K-row of padding that the v3 loader can step through
 
 __device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
@@ -683,7 +684,9 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
 
     const half_t* Ab = p.A + (long long)z * p.sA;
     const half_t* Wb = p.W + (long long)z * p.sW;
-    const half_t* zp = reinterpret_cast<const half_t*>(g_zero_page);
+    // Out-of-range sources point into a 64 KB run of zeros and are STEPPED like real ones (K * 2 bytes <= its size, checked at
+    // launch), so the steady-state loader has no per-load select: every pointer advances by the same scalar stride.
+    const half_t* zp = reinterpret_cast<const half_t*>(g_zero_row);
     const int Cin = p.C1 + p.C2;
 
     int a_lc[A_IT];
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
                 sx = (int)((long long)ix * p.Ws / p.Wv);
             }
             a_val[i] = ok;
-            a_ptr[i] = ok ? src + (((long long)a_img[i] * p.Hs + sy) * p.Ws + sx) * Cs + cl + a_lc[i] * 8 : zp;
+            a_ptr[i] = ok ? src + (((long long)a_img[i] * p.Hs + sy) * p.Ws + sx) * Cs + cl + a_lc[i] * 8 : zp + a_lc[i] * 8;
         }
     };
     const half_t* b_ptr[B_IT];
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
         const int row = q >> 3;
         b_lc[i] = (q & 7) ^ (row & 7);
         b_ok[i] = n0 + row < p.n_valid;
-        b_ptr[i] = Wb + (long long)(b_ok[i] ? n0 + row : 0) * p.ldw + b_lc[i] * 8;
+        b_ptr[i] = b_ok[i] ? Wb + (long long)(n0 + row) * p.ldw + b_lc[i] * 8 : zp + b_lc[i] * 8;
     }
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     auto issue = [&](int kt, int st) {
@@ -756,24 +759,32 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
         const unsigned Bs = As + (unsigned)(BM * BK3) * 2u;
         const bool live = kt < kt_end;
         const int k0 = kt * BK3;
+        if (PF == 1 && !live) return;                 // two-stage ring waits with vmcnt(0): nothing to keep countable
+        if (PF == 1 && k0 + BK3 <= p.K) {             // steady state (wave-uniform): bare DMA issues + one pointer bump each
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const half_t* src;
-            if (CONV) src = (live && a_val[i]) ? a_ptr[i] : zp;
-            else src = (live && a_ok[i] && k0 + a_lc[i] * 8 < p.K) ? a_ptr[i] : zp;
-            glds16(src, As + (unsigned)(i * NT + wid * 64) * 16u);
-        }
+            for (int i = 0; i < A_IT; ++i) glds16(a_ptr[i], As + (unsigned)(i * NT + wid * 64) * 16u);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const half_t* src = (live && b_ok[i] && k0 + b_lc[i] * 8 < p.K) ? b_ptr[i] : zp;
-            glds16(src, Bs + (unsigned)(i * NT + wid * 64) * 16u);
+            for (int i = 0; i < B_IT; ++i) glds16(b_ptr[i], Bs + (unsigned)(i * NT + wid * 64) * 16u);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const half_t* src;
+                if (CONV) src = live ? a_ptr[i] : zp;
+                else src = (live && k0 + a_lc[i] * 8 < p.K) ? a_ptr[i] : zp;
+                glds16(src, As + (unsigned)(i * NT + wid * 64) * 16u);
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const half_t* src = (live && k0 + b_lc[i] * 8 < p.K) ? b_ptr[i] : zp;
+                glds16(src, Bs + (unsigned)(i * NT + wid * 64) * 16u);
+            }
         }
         if (CONV) {
             if (--seg_left <= 0) {
                 conv_seek(k0 + BK3);
             } else {
 #pragma unroll
-                for (int i = 0; i < A_IT; ++i) a_ptr[i] += a_val[i] ? BK3 : 0;
+                for (int i = 0; i < A_IT; ++i) a_ptr[i] += BK3;
             }
         } else {
 #pragma unroll
@@ -852,7 +863,13 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
         // slab kt+1: landed for this wave, then for all (and nobody reads slab kt's stage any more)
         wait_vmcnt<LPT * (PF - 1)>();
         __builtin_amdgcn_s_barrier();
+#if LD_DBG == 5
+        __builtin_amdgcn_s_setprio(1);
+#endif
         issue(kt + PF + 1, st);
+#if LD_DBG == 5
+        __builtin_amdgcn_s_setprio(0);
+#endif
         const int sn = (st + 1) & (NST - 1);
         read_frags(sn, 0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
@@ -968,7 +985,7 @@ void launch_cfg(const GemmParams& p, hipStream_t s) {
             hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, block, 0, s, p);
         else
             hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, block, 0, s, p);
-    } else if (v3_min_k() > 0 && p.K / sk >= v3_min_k()) {
+    } else if (v3_min_k() > 0 && p.K / sk >= v3_min_k() && p.K <= 32000) {   // K row of zeros (g_zero_row) must cover K
         if (v3_stages() == 4) {
             if (p.conv)
                 hipLaunchKernelGGL((gemm3_kernel<BM, BN, true, 4>), grid, block, 0, s, p);
