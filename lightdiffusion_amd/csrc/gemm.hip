@@ -10,6 +10,8 @@
 // time-embedding broadcast / SiLU / GEGLU / residual.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "gemm.h"
 #ifndef LD_DBG
 #define LD_DBG 0
@@ -648,13 +650,32 @@ __global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GemmParams p) {
 }
 
 // =====================================================================================================================
-// v3: the same LDS-DMA ring with 64-wide K slabs and ONE workgroup per CU (4 stages x (BM+BN) x 128 B = up to 147 KB).
-// One barrier per 2 k-steps (40 MFMAs per wave), fragments double-buffered at k-step granularity.  128-byte LDS rows use
-// the chunk ^ (row & 7) swizzle (conflict-free for the 16x16x32 fragment reads, as in v1).  Chosen for long-K problems.
+// v3: 64-wide K slabs, a TWO-stage LDS-DMA ring (2 x (BM+BN) x 128 B <= 73.7 KB) and two workgroups per CU.
+// One barrier per slab = per 2 k-steps (40 MFMAs per wave at 128x160), fragments double-buffered at k-step granularity,
+// 128-byte LDS rows with the chunk ^ (row & 7) swizzle (conflict-free 16x16x32 fragment reads).
+// The slab loop is written to carry (almost) no vector-ALU work, because on this chip a VALU instruction of one wave and
+// an MFMA of the other wave on the same SIMD do not overlap at equal priority (tools/micro/coexec.hip: sum, not max):
+//  * B (and A of a plain GEMM) are fetched as  scalar base + per-lane 32-bit offset  — the per-slab advance is two SALU adds
+//    instead of one 64-bit VALU add per load; rows beyond M / n_valid are clamped to a valid row (their outputs are never
+//    stored, resp. are the don't-care padding columns of V^T), so the steady state has no select either;
+//  * conv A keeps per-lane pointers (taps outside the image read a run of zeros that is stepped like real data);
+//  * every fragment read is  base VGPR + immediate offset;  the two base VGPRs flip between the stages by one add each.
+// A K that is not a multiple of 64 takes a select-per-load slow path on its last slab only (wave-uniform branch).
 // =====================================================================================================================
-template <int BM, int BN, bool CONV, int NST>
+__device__ __forceinline__ void glds16s(unsigned voff, const half_t* sbase, unsigned lds_base) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(sbase), "s"(lds_base)
+        : "memory");
+}
+
+template <int BM, int BN, bool CONV, int NST>   // NST = 2: two workgroups per CU;  NST = 4: one workgroup, three slabs in flight
 __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmParams p) {
     constexpr int BK3 = 64, PF = NST - 1;
+    static_assert(NST == 2 || NST == 4, "ring depth");
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int A_CH = BM * 8, B_CH = BN * 8;
@@ -684,26 +705,29 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
 
     const half_t* Ab = p.A + (long long)z * p.sA;
     const half_t* Wb = p.W + (long long)z * p.sW;
-    // Out-of-range sources point into a 64 KB run of zeros and are STEPPED like real ones (K * 2 bytes <= its size, checked at
-    // launch), so the steady-state loader has no per-load select: every pointer advances by the same scalar stride.
-    const half_t* zp = reinterpret_cast<const half_t*>(g_zero_row);
+    const half_t* zp = reinterpret_cast<const half_t*>(g_zero_row);   // 64 KB of zeros, stepped through like real data
     const int Cin = p.C1 + p.C2;
 
+    // ---- A loader state
     int a_lc[A_IT];
     bool a_ok[A_IT];
     int a_img[A_IT], a_iy0[A_IT], a_ix0[A_IT];
-    const half_t* a_ptr[A_IT];
-    bool a_val[A_IT];
+    const half_t* a_ptr[A_IT];     // CONV: per-lane source pointers
+    unsigned a_off[A_IT];          // plain GEMM: byte offset from the scalar base a_base
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int q = tid + i * NT;
         const int row = q >> 3;
         a_lc[i] = (q & 7) ^ (row & 7);
+#if LD_DBG == 6
+        const int m = row;            // every workgroup streams the SAME tile: all loads hit cache (latency probe)
+#else
         const int m = m0 + row;
+#endif
         a_ok[i] = m < p.M;
         a_img[i] = a_iy0[i] = a_ix0[i] = 0;
         a_ptr[i] = zp;
-        a_val[i] = false;
+        a_off[i] = 0;
         if (CONV) {
             const int hw = p.Ho * p.Wo;
             const int mm = a_ok[i] ? m : 0;
@@ -713,9 +737,10 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
             a_iy0[i] = oy * p.stride - p.pad;
             a_ix0[i] = ox * p.stride - p.pad;
         } else {
-            a_ptr[i] = Ab + (long long)(a_ok[i] ? m : 0) * p.lda + a_lc[i] * 8;
+            a_off[i] = (unsigned)(((long long)(a_ok[i] ? m : p.M - 1) * p.lda + a_lc[i] * 8) * 2);
         }
     }
+    const half_t* a_base = Ab + (long long)kt_begin * BK3;   // wave-uniform
     int seg_left = 0;
     auto conv_seek = [&](int k0) {
         const int tap = k0 / Cin;
@@ -738,45 +763,50 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
                 sy = (int)((long long)iy * p.Hs / p.Hv);
                 sx = (int)((long long)ix * p.Ws / p.Wv);
             }
-            a_val[i] = ok;
             a_ptr[i] = ok ? src + (((long long)a_img[i] * p.Hs + sy) * p.Ws + sx) * Cs + cl + a_lc[i] * 8 : zp + a_lc[i] * 8;
         }
     };
-    const half_t* b_ptr[B_IT];
-    bool b_ok[B_IT];
+    // ---- B loader state
+    unsigned b_off[B_IT];
     int b_lc[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int q = tid + i * NT;
         const int row = q >> 3;
         b_lc[i] = (q & 7) ^ (row & 7);
-        b_ok[i] = n0 + row < p.n_valid;
-        b_ptr[i] = b_ok[i] ? Wb + (long long)(n0 + row) * p.ldw + b_lc[i] * 8 : zp + b_lc[i] * 8;
+#if LD_DBG == 6
+        const int n = row;
+#else
+        const int n = n0 + row < p.n_valid ? n0 + row : p.n_valid - 1;
+#endif
+        b_off[i] = (unsigned)(((long long)n * p.ldw + b_lc[i] * 8) * 2);
     }
+    const half_t* b_base = Wb + (long long)kt_begin * BK3;   // wave-uniform
+
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    auto issue = [&](int kt, int st) {
-        const unsigned As = smem_base + (unsigned)(st * STAGE) * 2u;
+    auto issue = [&](int kt, int st) {   // st is a literal at every call site
+        if (kt >= kt_end) return;        // the consumer's wait is chosen from the number of slabs really in flight
+        const unsigned As = smem_base + (unsigned)(st * STAGE) * 2u + (unsigned)(wid * 64) * 16u;
         const unsigned Bs = As + (unsigned)(BM * BK3) * 2u;
-        const bool live = kt < kt_end;
         const int k0 = kt * BK3;
-        if (PF == 1 && !live) return;                 // two-stage ring waits with vmcnt(0): nothing to keep countable
-        if (PF == 1 && k0 + BK3 <= p.K) {             // steady state (wave-uniform): bare DMA issues + one pointer bump each
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) glds16(a_ptr[i], As + (unsigned)(i * NT + wid * 64) * 16u);
-#pragma unroll
-            for (int i = 0; i < B_IT; ++i) glds16(b_ptr[i], Bs + (unsigned)(i * NT + wid * 64) * 16u);
-        } else {
+        if (k0 + BK3 <= p.K) {           // steady state: bare DMA issues
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                const half_t* src;
-                if (CONV) src = live ? a_ptr[i] : zp;
-                else src = (live && k0 + a_lc[i] * 8 < p.K) ? a_ptr[i] : zp;
-                glds16(src, As + (unsigned)(i * NT + wid * 64) * 16u);
+                if (CONV) glds16(a_ptr[i], As + (unsigned)(i * NT) * 16u);
+                else glds16s(a_off[i], a_base, As + (unsigned)(i * NT) * 16u);
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) glds16s(b_off[i], b_base, Bs + (unsigned)(i * NT) * 16u);
+        } else {                         // ragged last slab of a K that is not a multiple of 64
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const half_t* src = CONV ? a_ptr[i] : reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(a_base) + a_off[i]);
+                glds16(k0 + a_lc[i] * 8 < p.K ? src : zp, As + (unsigned)(i * NT) * 16u);
             }
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
-                const half_t* src = (live && k0 + b_lc[i] * 8 < p.K) ? b_ptr[i] : zp;
-                glds16(src, Bs + (unsigned)(i * NT + wid * 64) * 16u);
+                const half_t* src = reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(b_base) + b_off[i]);
+                glds16(k0 + b_lc[i] * 8 < p.K ? src : zp, Bs + (unsigned)(i * NT) * 16u);
             }
         }
         if (CONV) {
@@ -787,27 +817,20 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
                 for (int i = 0; i < A_IT; ++i) a_ptr[i] += BK3;
             }
         } else {
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) a_ptr[i] += BK3;
+            a_base += BK3;
         }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) b_ptr[i] += BK3;
+        b_base += BK3;
     };
-    if (CONV) {
-        conv_seek(kt_begin * BK3);
-    } else {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) a_ptr[i] += (long long)kt_begin * BK3;
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) b_ptr[i] += (long long)kt_begin * BK3;
+    if (CONV) conv_seek(kt_begin * BK3);
 
     const int fr = lane & 15, fq = lane >> 4;
-    int a_row[TM], b_row[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) a_row[i] = wm0 + i * 16 + fr;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b_row[j] = wn0 + j * 16 + fr;
+    // fragment read bases (halfs, inside the stage being read): row&7 == fr&7 for every fragment row (wm0, wn0, 16*i are
+    // multiples of 8), so the swizzled chunk depends on the k-step only and every other term is an immediate offset.
+    // rd0 / rd1 = k-step 0 / 1 of the A rows; the B rows sit (BM + wn0 - wm0) rows further.  Both are flipped between the two
+    // stages by one add each per slab (the only vector-ALU work of the steady-state loop besides conv A's pointer bumps).
+    const half_t* rd0 = smem + (wm0 + fr) * BK3 + ((fq ^ (fr & 7)) << 3);
+    const half_t* rd1 = smem + (wm0 + fr) * BK3 + (((4 + fq) ^ (fr & 7)) << 3);
+    const int b_rel = (BM + wn0 - wm0) * BK3;   // wave-uniform
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -815,68 +838,60 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll
-    for (int t = 0; t < PF; ++t) issue(kt_begin + t, t);
-    constexpr int LPT = A_IT + B_IT;
-
     half8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    auto read_frags = [&](int stg, int kk, half8 (&fa)[TM], half8 (&fb)[TN]) {
-        const half_t* S = smem + stg * STAGE;
-#if LD_DBG == 1 || LD_DBG == 3
-        if (kk == 0 && stg == 0)
-#endif
+    auto read_frags = [&](const half_t* rd, half8 (&fa)[TM], half8 (&fb)[TN]) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = as_half8(ld16(S + BM * BK3 + b_row[j] * BK3 + (((kk * 4 + fq) ^ (b_row[j] & 7)) << 3)));
-#if LD_DBG == 3
-        if (kk == 0 && stg == 0)
-#endif
+        for (int j = 0; j < TN; ++j) fb[j] = as_half8(ld16(rd + b_rel + j * 16 * BK3));
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = as_half8(ld16(S + a_row[i] * BK3 + (((kk * 4 + fq) ^ (a_row[i] & 7)) << 3)));
+        for (int i = 0; i < TM; ++i) fa[i] = as_half8(ld16(rd + i * 16 * BK3));
     };
     auto mma = [&](const half8 (&fa)[TM], const half8 (&fb)[TN]) {
-#if LD_DBG == 2
-#pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[i % TN], fa[i], acc[i][0], 0, 0, 0);
-#pragma unroll
-        for (int j = 1; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[0], acc[0][j], 0, 0, 0);
-#else
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-#endif
     };
 
-    wait_vmcnt<LPT * (PF - 1)>();                    // slab kt_begin landed
+    constexpr int LPT = A_IT + B_IT;   // DMA instructions per wave per slab
+    // "slab kt has landed" = at most the loads of the slabs issued after it are still outstanding (they complete in order)
+    auto wait_slab = [&](int kt) {
+        if (PF == 1) {
+            wait_vmcnt<0>();
+        } else {
+            const int ahead = kt_end - 1 - kt;          // slabs issued after kt (at most PF - 1)
+            if (ahead >= PF - 1) wait_vmcnt<LPT*(PF - 1)>();
+            else if (ahead == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < PF; ++t) issue(kt_begin + t, t);
+    wait_slab(kt_begin);
     __builtin_amdgcn_s_barrier();
     issue(kt_begin + PF, PF);
-    read_frags(0, 0, fa0, fb0);
+    read_frags(rd0, fa0, fb0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int st = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        // k-step 0 of slab kt is in set 0: fetch k-step 1 of the same slab under its MFMAs
-        read_frags(st, 1, fa1, fb1);
+        // k-step 0 of slab kt sits in set 0; fetch k-step 1 under its MFMAs, then (slab kt+1 landed for everyone, stage st
+        // free) refill st with slab kt+NST and fetch k-step 0 of slab kt+1 under the k-step-1 MFMAs
+        read_frags(rd1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         mma(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // slab kt+1: landed for this wave, then for all (and nobody reads slab kt's stage any more)
-        wait_vmcnt<LPT * (PF - 1)>();
+        wait_slab(kt + 1);
         __builtin_amdgcn_s_barrier();
-#if LD_DBG == 5
-        __builtin_amdgcn_s_setprio(1);
-#endif
-        issue(kt + PF + 1, st);
-#if LD_DBG == 5
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        const int sn = (st + 1) & (NST - 1);
-        read_frags(sn, 0, fa0, fb0);
+        issue(kt + NST, st);
+        const int flip = (st == NST - 1) ? -(NST - 1) * STAGE : STAGE;   // halfs to the next stage of the ring
+        rd0 += flip;
+        rd1 += flip;
+        st = (st + 1) & (NST - 1);
+        read_frags(rd0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         mma(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        st = sn;
     }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -912,6 +927,263 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
         }
     }
     __syncthreads();
+    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid);
+}
+
+// =====================================================================================================================
+// v4: the v3 tile with the roles split over 8 waves ("producer / consumer").  Waves 0-3 only read fragments and issue MFMAs;
+// waves 4-7 only issue the LDS-DMA for the slab ring (the loads wave w-4 issues in v3).  Why: an LDS-DMA instruction costs its
+// wave 60-180 issue cycles (microarch guide) and a wave issues in order, so in v3 each slab's 9 DMA issues sit in front of the
+// same wave's 40 MFMAs — a lone workgroup on a CU spends ~0.75 us per slab, 0.3 us of it in MFMAs (tools/gemm_micro.py small).
+// With the split the DMA issue runs on the other wave of each SIMD, and the ring is 4 deep (one workgroup per CU: 147 KB),
+// so three slabs are in flight.  One s_barrier per slab joins all 8 waves:
+//   consumer kt:  read k-step-1 frags of slab kt | MFMA k-step 0 | lgkmcnt(0) | BARRIER kt | read k-step-0 frags of kt+1 | MFMA k-step 1
+//   producer kt:  wait until slab kt+1 has landed (counted vmcnt)             | BARRIER kt | issue slab kt+4 into the stage of kt
+// After BARRIER kt slab kt+1 is complete for everyone and nobody reads slab kt's stage any more.
+// =====================================================================================================================
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
+    constexpr int BK3 = 64, NST = 4;
+    constexpr int WTM = BM / 2, WTN = BN / 2;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "whole instructions per wave");
+    constexpr int LPT = A_IT + B_IT;
+    constexpr int STAGE = (BM + BN) * BK3;
+    constexpr int CLD = BN + 8;
+    static_assert(BM * CLD <= NST * STAGE, "epilogue tile must fit in the ring");
+    __shared__ __attribute__((aligned(16))) half_t smem[NST * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wid8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wid8 >= 4;
+    const int wid = wid8 & 3;
+    const int tid = wid * 64 + lane;          // 0..255 inside the role
+    const int z = blockIdx.z;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles = tiles_m * tiles_n;
+    const int splitk = p.splitk > 1 ? p.splitk : 1;
+    int bid = xcd_remap(blockIdx.x, tiles * splitk);
+    const int ks = bid / tiles;
+    bid -= ks * tiles;
+    const int tn_i = p.m_fastest ? bid / tiles_m : bid % tiles_n;
+    const int tm_i = p.m_fastest ? bid % tiles_m : bid / tiles_n;
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int KT = (p.K + BK3 - 1) / BK3;
+    const int kt_begin = (int)((long long)ks * KT / splitk), kt_end = (int)((long long)(ks + 1) * KT / splitk);
+
+    if (producer) {
+        // ------------------------------------------------------------------ producer: the v3 loader, nothing else
+        const half_t* Ab = p.A + (long long)z * p.sA;
+        const half_t* Wb = p.W + (long long)z * p.sW;
+        const half_t* zp = reinterpret_cast<const half_t*>(g_zero_row);
+        const int Cin = p.C1 + p.C2;
+        int a_lc[A_IT];
+        bool a_ok[A_IT];
+        int a_img[A_IT], a_iy0[A_IT], a_ix0[A_IT];
+        const half_t* a_ptr[A_IT];
+        unsigned a_off[A_IT];
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            const int q = tid + i * NT;
+            const int row = q >> 3;
+            a_lc[i] = (q & 7) ^ (row & 7);
+            const int m = m0 + row;
+            a_ok[i] = m < p.M;
+            a_img[i] = a_iy0[i] = a_ix0[i] = 0;
+            a_ptr[i] = zp;
+            a_off[i] = 0;
+            if (CONV) {
+                const int hw = p.Ho * p.Wo;
+                const int mm = a_ok[i] ? m : 0;
+                const int img = mm / hw, rem = mm - img * hw;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                a_img[i] = img;
+                a_iy0[i] = oy * p.stride - p.pad;
+                a_ix0[i] = ox * p.stride - p.pad;
+            } else {
+                a_off[i] = (unsigned)(((long long)(a_ok[i] ? m : p.M - 1) * p.lda + a_lc[i] * 8) * 2);
+            }
+        }
+        const half_t* a_base = Ab + (long long)kt_begin * BK3;
+        int seg_left = 0;
+        auto conv_seek = [&](int k0) {
+            const int tap = k0 / Cin;
+            const int c0 = k0 - tap * Cin;
+            const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+            const bool second = c0 >= p.C1;
+            const half_t* src = second ? p.A2 : Ab;
+            const int Cs = second ? p.C2 : p.C1;
+            const int cl = second ? c0 - p.C1 : c0;
+            seg_left = ((second ? Cin : p.C1) - c0) / BK3;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv && tap < p.ksize * p.ksize;
+                int sy = iy, sx = ix;
+                if (p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws) {
+                    sy = iy >> 1;
+                    sx = ix >> 1;
+                } else if (p.Hv != p.Hs || p.Wv != p.Ws) {
+                    sy = (int)((long long)iy * p.Hs / p.Hv);
+                    sx = (int)((long long)ix * p.Ws / p.Wv);
+                }
+                a_ptr[i] = ok ? src + (((long long)a_img[i] * p.Hs + sy) * p.Ws + sx) * Cs + cl + a_lc[i] * 8 : zp + a_lc[i] * 8;
+            }
+        };
+        unsigned b_off[B_IT];
+        int b_lc[B_IT];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            const int q = tid + i * NT;
+            const int row = q >> 3;
+            b_lc[i] = (q & 7) ^ (row & 7);
+            const int n = n0 + row < p.n_valid ? n0 + row : p.n_valid - 1;
+            b_off[i] = (unsigned)(((long long)n * p.ldw + b_lc[i] * 8) * 2);
+        }
+        const half_t* b_base = Wb + (long long)kt_begin * BK3;
+        const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+        auto issue = [&](int kt) {
+            if (kt >= kt_end) return;
+            const int st = (kt - kt_begin) & (NST - 1);
+            const unsigned As = smem_base + (unsigned)(st * STAGE) * 2u + (unsigned)(wid * 64) * 16u;
+            const unsigned Bs = As + (unsigned)(BM * BK3) * 2u;
+            const int k0 = kt * BK3;
+            if (k0 + BK3 <= p.K) {
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) {
+                    if (CONV) glds16(a_ptr[i], As + (unsigned)(i * NT) * 16u);
+                    else glds16s(a_off[i], a_base, As + (unsigned)(i * NT) * 16u);
+                }
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i) glds16s(b_off[i], b_base, Bs + (unsigned)(i * NT) * 16u);
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) {
+                    const half_t* src = CONV ? a_ptr[i] : reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(a_base) + a_off[i]);
+                    glds16(k0 + a_lc[i] * 8 < p.K ? src : zp, As + (unsigned)(i * NT) * 16u);
+                }
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i) {
+                    const half_t* src = reinterpret_cast<const half_t*>(reinterpret_cast<const char*>(b_base) + b_off[i]);
+                    glds16(k0 + b_lc[i] * 8 < p.K ? src : zp, Bs + (unsigned)(i * NT) * 16u);
+                }
+            }
+            if (CONV) {
+                if (--seg_left <= 0) {
+                    conv_seek(k0 + BK3);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < A_IT; ++i) a_ptr[i] += BK3;
+                }
+            } else {
+                a_base += BK3;
+            }
+            b_base += BK3;
+        };
+        // slab kt has landed once at most the loads of the slabs issued after it are outstanding (in-order completion)
+        auto wait_slab = [&](int kt, int issued_after) {
+            int ahead = kt_end - 1 - kt;
+            if (ahead > issued_after) ahead = issued_after;
+            if (ahead >= 3) wait_vmcnt<3 * LPT>();
+            else if (ahead == 2) wait_vmcnt<2 * LPT>();
+            else if (ahead == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
+        };
+        if (CONV) conv_seek(kt_begin * BK3);
+#pragma unroll
+        for (int t = 0; t < NST; ++t) issue(kt_begin + t);
+        wait_slab(kt_begin, NST - 1);
+        __builtin_amdgcn_s_barrier();                    // P: slab kt_begin is readable
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            wait_slab(kt + 1, NST - 2);                  // issued so far: up to kt + NST - 1
+            __builtin_amdgcn_s_barrier();                // BARRIER kt
+            issue(kt + NST);
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                    // tail barrier (pairs with the consumers' before the epilogue)
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
+    const int fr = lane & 15, fq = lane >> 4;
+    const half_t* rd0 = smem + (wm0 + fr) * BK3 + ((fq ^ (fr & 7)) << 3);
+    const half_t* rd1 = smem + (wm0 + fr) * BK3 + (((4 + fq) ^ (fr & 7)) << 3);
+    const int b_rel = (BM + wn0 - wm0) * BK3;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    half8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto read_frags = [&](const half_t* rd, half8 (&fa)[TM], half8 (&fb)[TN]) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = as_half8(ld16(rd + b_rel + j * 16 * BK3));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = as_half8(ld16(rd + i * 16 * BK3));
+    };
+    auto mma = [&](const half8 (&fa)[TM], const half8 (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_barrier();                        // P
+    read_frags(rd0, fa0, fb0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int st = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        read_frags(rd1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // BARRIER kt
+        const int flip = (st == NST - 1) ? -(NST - 1) * STAGE : STAGE;
+        rd0 += flip;
+        rd1 += flip;
+        st = (st + 1) & (NST - 1);
+        read_frags(rd0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                        // tail: the ring is quiet, producers leave
+
+    if (splitk > 1) {
+        float* part = p.partial + (long long)ks * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm0 + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn0 + j * 16 + fq * 4;
+                if (m < p.M && n < p.N) {
+                    f32x4 v = acc[i][j];
+                    v *= p.alpha;
+                    *reinterpret_cast<f32x4*>(part + (long long)m * p.N + n) = v;
+                }
+            }
+        }
+        return;
+    }
+    half_t* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm0 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn0 + j * 16 + fq * 4;
+            half4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] * p.alpha);
+            *reinterpret_cast<half4*>(Cs + ml * CLD + nl) = h;
+        }
+    }
+    __syncthreads();                                     // consumers only: the producers have exited
     epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid);
 }
 
@@ -970,10 +1242,6 @@ int v3_min_k() {   // K from which the 64-wide-slab kernel (v3) is used instead 
     static const int v = getenv("LD_GEMM_V3_MINK") ? atoi(getenv("LD_GEMM_V3_MINK")) : 1;
     return v;
 }
-int v3_stages() {  // 2: two-stage ring, 2 blocks/CU;  4: four-stage ring, 1 block/CU
-    static const int v = getenv("LD_GEMM_V3_NST") ? atoi(getenv("LD_GEMM_V3_NST")) : 2;
-    return v;
-}
 
 template <int BM, int BN>
 void launch_cfg(const GemmParams& p, hipStream_t s) {
@@ -986,7 +1254,20 @@ void launch_cfg(const GemmParams& p, hipStream_t s) {
         else
             hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, block, 0, s, p);
     } else if (v3_min_k() > 0 && p.K / sk >= v3_min_k() && p.K <= 32000) {   // K row of zeros (g_zero_row) must cover K
-        if (v3_stages() == 4) {
+        // producer/consumer kernel: wins where a plain GEMM leaves at most one workgroup per CU (batch-1 step: +5.6 % whole
+        // step, same box A/B); loses on convs and wherever two v3 workgroups share a CU.  LD_GEMM_V4 = 0 never, 1 always.
+        static const int env_v4 = getenv("LD_GEMM_V4") ? atoi(getenv("LD_GEMM_V4")) : -1;
+        if (env_v4 == 1 || (env_v4 < 0 && !p.conv && (long long)tiles * sk * p.batch <= 256)) {
+            dim3 block8(2 * NT);
+            if (p.conv)
+                hipLaunchKernelGGL((gemm4_kernel<BM, BN, true>), grid, block8, 0, s, p);
+            else
+                hipLaunchKernelGGL((gemm4_kernel<BM, BN, false>), grid, block8, 0, s, p);
+            return;
+        }
+        static const int env_nst = getenv("LD_GEMM_V3_NST") ? atoi(getenv("LD_GEMM_V3_NST")) : 0;   // A/B knob
+        const bool deep = env_nst == 4;   // measured (tools/gemm_micro.py small): no gain for lone workgroups, so never automatic
+        if (deep) {
             if (p.conv)
                 hipLaunchKernelGGL((gemm3_kernel<BM, BN, true, 4>), grid, block, 0, s, p);
             else
