@@ -182,7 +182,7 @@ def main():
         "cond_broadcast_ms": 1e3 * t_bcast,
         "weights_load_s": t_load, "finite": finite,
         "kernel_ms_per_forward": {k: round(v[0], 4) for k, v in prof.items()},
-        "roofline": {"kernel": f"gemm_kernel ({dom})", "bound": "mfma", "achieved": d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0,
+        "roofline": {"kernel": f"gemm3_kernel / gemm4_kernel family, launch class '{dom}'", "bound": "mfma", "achieved": d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0,
                      "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
                      "frac": (d_fl / (d_ms * 1e-3)) / MFMA_PEAK_F16 if d_ms > 0 else 0.0, "traffic": None,
                      "launches": d_n, "avg_launch_us": 1e3 * d_ms / max(d_n, 1), "flops_per_launch": d_fl / max(d_n, 1)},

@@ -11,13 +11,22 @@ raw.ld_debug_gemm_override.argtypes = [ctypes.c_int, ctypes.c_int]
 DEV = "cuda:0"
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 
-def timeit(fn, reps=20):
-    fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps): fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e3
+def timeit(fn, reps=10):
+    """GPU time per call, launches replayed from a hipGraph: from Python the small shapes are host-bound (~12 us per call)."""
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        fn(); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            for _ in range(reps): fn()
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        g.replay(); g.replay()
+        e1.record(st); torch.cuda.synchronize()
+    del g
+    return e0.elapsed_time(e1) / (2 * reps) * 1e3
 
 def sweep(name, fn, flops):
     res = []
