@@ -403,10 +403,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
         __builtin_amdgcn_s_barrier();      // ... everyone's has, and nobody still reads tile t-1's buffer
         if (t + 1 < ntiles) issue(key0 + KT, (t + 1) & 1);
         const half_t* T = smem + (t & 1) * BUF_H;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            if (MASKED && key0 + sub * 32 >= p.Lk) break;   // wave-uniform: nothing valid in this half tile
-            f32x16 s;
+        // S^T of one 32-key subtile, already relative to the softmax reference: -m_ref is the C operand of the first k-step.
+        // That first MFMA is written in asm: D (early-clobber) != C pins the three-address form, so -m_ref is read in place;
+        // through the builtin hipcc ties D to C and copies the 16 reference registers.  (Hazards: the next reader of s is the
+        // following MFMA with C == D — no wait states; the VALU readers come after builtin MFMAs, which the compiler's hazard
+        // recogniser spaces as usual.  DK == 1 has no builtin MFMA behind the asm one, so it uses the builtin.)
+        auto qk = [&](int sub, f32x16& s) {
 #pragma unroll
             for (int ks = 0; ks < DK; ++ks) {
 #if LD_ATT_DBG == 4
@@ -414,11 +416,6 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
 #else
                 const half8 kf = as_half8(ld16(T + sub * 32 * d + koff[ks]));
 #endif
-                // first k-step in asm: D (early-clobber) != C pins the three-address form, so -m_ref is read in place as C;
-                // through the builtin hipcc ties D to C and copies the 16 reference registers every other subtile.
-                // (Hazards: the next reader of s is the following MFMA with C == D — no wait states; the VALU readers
-                // come after builtin MFMAs, which the compiler's hazard recogniser spaces as usual.)
-                // DK == 1 has no builtin MFMA behind the asm one, so nothing would space the VALU readers: builtin there.
                 if (ks == 0 && DK == 1) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], negm, 0, 0, 0);
                 else if (ks == 0) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s) : "v"(kf), "v"(qf[0]), "v"(negm));
                 else s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
@@ -441,10 +438,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
                     }
                 }
             }
+        };
+        // softmax of one subtile and its O^T += V^T P^T.  `ahead` = an S^T tile that was already produced against the current
+        // reference (the next subtile's): it follows when the reference moves.
+        auto finish = [&](int sub, f32x16& s, f32x16* ahead, bool first) {
             // Softmax runs at raised wave priority.  Measured on this chip (tools/micro/coexec.hip): a VALU stream and an MFMA
             // stream of two waves on one SIMD take the SUM of their times at equal priority (the MFMA wave holds the vector
-            // issue port while the matrix pipe is busy) and the MAX when the VALU wave has priority 1 — so the wave that is in
-            // its exp/max phase goes first and the other resident waves' MFMAs fill the matrix pipe underneath it.
+            // issue port while the matrix pipe is busy) and the MAX when the VALU wave has priority 1.
             __builtin_amdgcn_s_setprio(1);
             // 16 -> 1 by v_max3_f32 (this file is built with -fno-honor-nans: otherwise fmaxf() adds a NaN-quieting
             // v_max x,x per MFMA output), then the other half-wave (the other 16 keys of the same query) by one
@@ -457,14 +457,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
                 mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
-            const bool first = (t == 0 && sub == 0);   // the reference starts at 0: the first tile moves it to its own maximum
-            if (first || __any(mx > TAU)) {
+            if (first || __any(mx > TAU)) {   // `first`: the reference starts at 0, the first subtile moves it to its own maximum
                 const float delta = first ? mx : (mx > TAU ? mx : 0.f);
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 m_ref += delta;
                 l_run *= alpha;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[e] -= delta;
+                if (ahead != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) (*ahead)[e] -= delta;
+                }
                 {   // in-place (tied asm operand): keeps -m_ref in ONE register tile across both arms of this branch, otherwise
                     // the allocator gives each arm its own tile and copies 16 registers on the common path
                     const float nm = -m_ref;
@@ -500,6 +503,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
 #endif
                     o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[k2], o[tt], 0, 0, 0);
                 }
+        };
+        // (issuing both QK^T products of a tile ahead of the two softmaxes — so that they execute underneath this wave's own
+        // VALU work — measured no different: 559 vs 558 us at L=4096, d=40; the resident waves already interleave.)
+        {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                if (MASKED && key0 + sub * 32 >= p.Lk) break;   // wave-uniform: nothing valid in this half tile
+                f32x16 s;
+                qk(sub, s);
+                finish(sub, s, nullptr, t == 0 && sub == 0);
+            }
         }
     }
 
