@@ -1244,6 +1244,21 @@ int v3_min_k() {   // K from which the 64-wide-slab kernel (v3) is used instead 
 }
 
 template <int BM, int BN>
+void launch_cfg_v34(const GemmParams& p, hipStream_t s) {   // tile shapes that only the v3 / v4 kernels are instantiated for
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int sk = p.splitk > 1 ? p.splitk : 1;
+    dim3 grid(tiles * sk, 1, p.batch);
+    static const int env_v4 = getenv("LD_GEMM_V4") ? atoi(getenv("LD_GEMM_V4")) : -1;
+    if (env_v4 == 1 || (env_v4 < 0 && !p.conv && (long long)tiles * sk * p.batch <= 256)) {
+        if (p.conv) hipLaunchKernelGGL((gemm4_kernel<BM, BN, true>), grid, dim3(2 * NT), 0, s, p);
+        else hipLaunchKernelGGL((gemm4_kernel<BM, BN, false>), grid, dim3(2 * NT), 0, s, p);
+    } else {
+        if (p.conv) hipLaunchKernelGGL((gemm3_kernel<BM, BN, true, 2>), grid, dim3(NT), 0, s, p);
+        else hipLaunchKernelGGL((gemm3_kernel<BM, BN, false, 2>), grid, dim3(NT), 0, s, p);
+    }
+}
+
+template <int BM, int BN>
 void launch_cfg(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int sk = p.splitk > 1 ? p.splitk : 1;
@@ -1321,7 +1336,18 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (env_bm && p.bm == 0) p.bm = env_bm;
     if (env_bn && p.bn == 0 && p.act != 2) p.bn = env_bn;
     int bn = p.bn ? p.bn : gemm_pick_bn(p.N);
-    if (bn != 128 && bn != 160) return LD_ERR_ARG;
+    // Skinny plain GEMMs (the batch-1 step's M = 128..2048 projections): with <= 128 tiles of 64 x 160 most CUs idle while
+    // each busy one streams 28.7 KB per slab through its one LDS-DMA path; 64 x 64 tiles spread the same work over 2.5x more CUs
+    // at 16 KB per slab: 512x1280x1280 12.8 -> 8.0 us, 128x1280x1280 12.4 -> 7.6 us; batch-1 step +6 % (same box), batch 8 neutral.
+    // v3 / v4 kernels only.  Measured no better: the same for convs (their split-K already fills the chip: 156.5 vs 163.0
+    // steps/s), 32-row tiles below it (166.2 vs 165.8).
+    static const int skinny_max = getenv("LD_GEMM_SKINNY") ? atoi(getenv("LD_GEMM_SKINNY")) : 256;   // A/B knob: tile-count threshold, 0 = never
+    const bool skinny_ok = !p.conv && p.act != 2 && p.bn == 0 && p.bm == 0 && (p.N % 64) == 0 && !use_v1() && v3_min_k() > 0 && p.K <= 32000;
+    if (skinny_ok) {
+        const long long t160 = (long long)((p.M + 63) / 64) * ((p.N + bn - 1) / bn) * p.batch;
+        if (t160 <= skinny_max) bn = 64;
+    }
+    if (bn != 128 && bn != 160 && bn != 64) return LD_ERR_ARG;
     if (p.act == 2 && (p.N % bn)) return LD_ERR_SHAPE;
     const int tiles_n = (p.N + bn - 1) / bn;
     const int KT = (p.K + BK - 1) / BK;          // 64-wide K slabs
@@ -1340,6 +1366,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         else if (p.K >= 4096 && tiles128 >= 32 && can_split) bm = 128;
         else bm = 64;
     }
+    if (bn == 64) bm = 64;
     if (bm != 64 && bm != 128) return LD_ERR_ARG;
     const int tiles = ((p.M + bm - 1) / bm) * tiles_n;
     if (sk == 0) {
@@ -1369,7 +1396,8 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     // M panel re-read the same activations through the XCD's L2, which matters more than re-streaming the weights
     if (p.m_fastest < 0) p.m_fastest = 0;
 
-    if (bm == 128 && bn == 160) launch_cfg<128, 160>(p, stream);
+    if (bn == 64) launch_cfg_v34<64, 64>(p, stream);
+    else if (bm == 128 && bn == 160) launch_cfg<128, 160>(p, stream);
     else if (bm == 128 && bn == 128) launch_cfg<128, 128>(p, stream);
     else if (bm == 64 && bn == 160) launch_cfg<64, 160>(p, stream);
     else launch_cfg<64, 128>(p, stream);
