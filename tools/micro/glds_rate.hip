@@ -13,7 +13,8 @@ __device__ __forceinline__ void glds16s(unsigned voff, const void* sbase, unsign
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
 }
 
-template <int MODE>   // 0: strided rows, per-lane ptr; 1: contiguous, per-lane ptr; 2: strided rows, saddr; 3: plain loads to VGPR (strided); 4: glds dword (4 B/lane) contiguous
+template <int MODE, int WRAP = 8>   // WRAP: slab positions cycled through (8: cache-resident; 176: the whole 23040-byte row, streamed)
+// 0: strided rows, per-lane ptr; 1: contiguous, per-lane ptr; 2: strided rows, saddr; 3: plain loads to VGPR (strided); 4: glds dword (4 B/lane) contiguous
 __global__ __launch_bounds__(256, 2) void pull(const char* src, size_t row_stride, size_t span, int iters, float* out) {
     __shared__ __attribute__((aligned(16))) char smem[2][36864];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -35,14 +36,14 @@ __global__ __launch_bounds__(256, 2) void pull(const char* src, size_t row_strid
         const unsigned st = base + (it & 1) * 36864 + wid * 1024;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            if (MODE == 0 || MODE == 1) glds16(p[i] + (size_t)(it & 7) * 128, st + i * 4096);
+            if (MODE == 0 || MODE == 1) glds16(p[i] + (size_t)(it % WRAP) * 128, st + i * 4096);
             if (MODE == 2) glds16s(off[i], sb, st + i * 4096);
             if (MODE == 3) {
-                const uint4 v = *reinterpret_cast<const uint4*>(p[i] + (size_t)(it & 7) * 128);
+                const uint4 v = *reinterpret_cast<const uint4*>(p[i] + (size_t)(it % WRAP) * 128);
                 acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
             }
         }
-        if (MODE == 2) sb = blk + (size_t)((it + 1) & 7) * 128;
+        if (MODE == 2) sb = blk + (size_t)((it + 1) % WRAP) * 128;
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // one slab in flight behind the one being issued
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -50,20 +51,20 @@ __global__ __launch_bounds__(256, 2) void pull(const char* src, size_t row_strid
     out[blockIdx.x * 256 + tid] = (float)smem[0][tid] + (float)(acc.x ^ acc.y ^ acc.z ^ acc.w);
 }
 
-template <int MODE>
+template <int MODE, int WRAP = 8>
 void run(const char* name, int blocks_per_cu, size_t row_stride) {
     char* src; float* out;
-    const size_t span = 288 * (row_stride ? row_stride : 128) + 8192;   // rows 0..287 + the 8 x 128 B slab offsets + slack
+    const size_t span = 288 * (row_stride ? row_stride : 128) + 8192 + (size_t)WRAP * 128;   // rows 0..287 + the 8 x 128 B slab offsets + slack
     const size_t total = 64 * span + (1 << 20);
     if (hipMalloc(&src, total) != hipSuccess) { printf("alloc failed\n"); return; }
     (void)hipMemset(src, 1, total);
     (void)hipMalloc(&out, 512 * 256 * 4);
     const int iters = 4000, blocks = 256 * blocks_per_cu;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    pull<MODE><<<blocks, 256>>>(src, row_stride, span, iters, out);
+    pull<MODE, WRAP><<<blocks, 256>>>(src, row_stride, span, iters, out);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    pull<MODE><<<blocks, 256>>>(src, row_stride, span, iters, out);
+    pull<MODE, WRAP><<<blocks, 256>>>(src, row_stride, span, iters, out);
     (void)hipEventRecord(e1);
     (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -79,6 +80,8 @@ int main() {
         run<1>("LDS-DMA, contiguous 1 KB / instr, vaddr", b, 0);
         run<2>("LDS-DMA, 128 B rows (stride 2560 B), saddr", b, 2560);
         run<3>("global_load_dwordx4 -> VGPR, 128 B rows", b, 2560);
+        run<0, 176>("LDS-DMA, 23040 B rows STREAMED (425 MB set)", b, 23040);
+        run<2, 176>("LDS-DMA saddr, 23040 B rows STREAMED", b, 23040);
     }
     return 0;
 }
