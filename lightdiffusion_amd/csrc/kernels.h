@@ -1,13 +1,18 @@
 // Launcher declarations for the gfx950 kernels (internal to the shared library; the public C ABI is
 // include/ld_mi355x.h).  Every launcher validates shapes on the host and returns an LD_* status.
 #pragma once
+#include <cstdlib>
 #include "common.h"
 #include "gemm.h"
 
 // ---- norm.hip
 // pixel chunks per image: aim at ~2048 blocks (x 4 channel slabs x n images), at least 8 pixels per chunk, at most 256 chunks
 static inline int gn_num_chunks(int n_img, int HW) {
-    int p = 2048 / (4 * (n_img < 1 ? 1 : n_img));
+    // workgroups per launch, measured (profiles/README.md): 512 is best at UNet batch 2 (GroupNorm 0.92 -> 0.74 ms per forward),
+    // 1024 at UNet batch 16 (1.51 -> 1.40 ms); LD_GN_BLOCKS overrides (A/B knob)
+    static const int env_target = getenv("LD_GN_BLOCKS") ? atoi(getenv("LD_GN_BLOCKS")) : 0;
+    const int target = env_target ? env_target : (n_img <= 4 ? 512 : 1024);
+    int p = target / (4 * (n_img < 1 ? 1 : n_img));
     if (p > HW / 8) p = HW / 8;
     if (p > 256) p = 256;
     return p < 1 ? 1 : p;
