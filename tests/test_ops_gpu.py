@@ -156,7 +156,8 @@ def test_layernorm(ops, rows, c):
 
 @pytest.mark.parametrize("b,heads,lq,lk,d", [
     (2, 8, 256, 256, 40), (1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160), (2, 8, 64, 64, 160),
-    (2, 8, 100, 77, 40), (2, 8, 1024, 77, 80), (1, 8, 64, 77, 160), (2, 8, 192, 192, 8), (1, 4, 130, 200, 32), (2, 2, 70, 154, 64)])
+    (2, 8, 100, 77, 40), (2, 8, 1024, 77, 80), (1, 8, 64, 77, 160), (2, 8, 192, 192, 8), (1, 4, 130, 200, 32), (2, 2, 70, 154, 64),
+    (8, 8, 2304, 2304, 40), (8, 8, 2200, 2200, 40)])   # last two: the 8-wave (256-query) workgroup variant, unmasked and ragged
 def test_attention(ops, b, heads, lq, lk, d):
     c = heads * d
     q, k, v = r16((b, lq, c), 51), r16((b, lk, c), 52), r16((b, lk, c), 53)
