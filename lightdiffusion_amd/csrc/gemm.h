@@ -41,7 +41,22 @@ struct GemmParams {
     int m_fastest = -1;          // tile order: -1 auto, 0 n fastest, 1 m fastest
     float* partial = nullptr;    // split-K workspace, >= splitk*M*N floats
     size_t partial_bytes = 0;
+    // ---- LayerNorm folded into the contractions around it (v3 / v4 kernels, no split-K; unet.hip "ln fold"):
+    //   producer (the GEMM that writes the residual stream): per output row and N tile, (sum, sum of squares) of the fp16 outputs
+    float* stat_out = nullptr;       // [tiles_n][M][2] floats
+    int* stat_parts_out = nullptr;   // host int: gemm_launch stores the number of N tiles (parts) it used
+    //   consumer (a projection of LN(x), with gamma folded into W and beta into the bias at load time):
+    //   out = rstd_row * (acc - mu_row * wsum[n]) + bias'[n]; with ln_swapped the LN rows are this GEMM's COLUMNS (V^T = Wv · x^T)
+    const float* ln_stat = nullptr;  // the producer's stat_out
+    int ln_parts = 0;                // its N tiles
+    int ln_rows = 0;                 // its M (row stride of one part)
+    int ln_zrows = 0;                // ln_swapped: LN rows per batch element z (row = z*ln_zrows + column)
+    float ln_inv_c = 0.f, ln_eps = 0.f;
+    const float* ln_wsum = nullptr;  // per output feature: sum_k of the folded weight row ([N], or [M] when ln_swapped)
+    int ln_swapped = 0;
 };
+
+bool gemm_ln_fold_available();   // the kernels that implement stat_out / ln_stat are the ones gemm_launch will pick
 
 // BN the GEGLU weight interleave must use for a projection with N (=2*inner) output rows
 static inline int gemm_pick_bn(int N) { return (N % 160 == 0) ? 160 : 128; }

@@ -62,7 +62,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int 
 // loads overlap each other instead of paying one full memory latency per chunk (the accumulators are dead here, so
 // the registers are free).
 template <int BM, int BN>
-__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t* Cs, int z, int m0, int n0, int tid) {
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t* Cs, int z, int m0, int n0, int tid, float* lds_scratch = nullptr) {
     constexpr int CLD = BN + 8;
     if (p.act == 2) {
         constexpr int CPR = BN / 16;
@@ -132,8 +132,91 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
                         else if (p.act == 3) t = quick_gelu_f(t);
                         v[j] = t + r[j];
                     }
-                    st16(p.C + (long long)z * p.sC + (long long)m * p.ldc + n, pack8(v));
+                    const uint4 packed = pack8(v);
+                    st16(p.C + (long long)z * p.sC + (long long)m * p.ldc + n, packed);
+                    if (lds_scratch != nullptr) {   // LN-fold producer: row statistics of what was actually stored (the fp16 values)
+                        float f[8];
+                        unpack8(packed, f);
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            s1 += f[j];
+                            s2 += f[j] * f[j];
+                        }
+                        lds_scratch[q * 2] = s1;
+                        lds_scratch[q * 2 + 1] = s2;
+                    }
+                } else if (lds_scratch != nullptr && (g0 + k) < EIT && q < BM * CPR) {
+                    lds_scratch[q * 2] = 0.f;
+                    lds_scratch[q * 2 + 1] = 0.f;
                 }
+            }
+        }
+        if (lds_scratch != nullptr) {   // one owner per row sums its CPR chunk partials in chunk order (bitwise reproducible)
+            __syncthreads();
+            if (tid < BM && m0 + tid < p.M) {
+                float s1 = 0.f, s2 = 0.f;
+                for (int c = 0; c < CPR; ++c) {
+                    s1 += lds_scratch[(tid * CPR + c) * 2];
+                    s2 += lds_scratch[(tid * CPR + c) * 2 + 1];
+                }
+                float* o = p.stat_out + ((long long)(n0 / BN) * p.M + m0 + tid) * 2;
+                o[0] = s1;
+                o[1] = s2;
+            }
+        }
+    }
+}
+
+// ---- LN fold, consumer side (v3 / v4).  ln_prepare: one thread per LN row of the tile finishes (mu, rstd) from the producer's
+// per-N-tile partials, in part order, into LDS; ln_apply: acc <- rstd * (acc - mu * wsum) in fp32, before the tile is rounded to fp16.
+template <int BM, int BN>
+__device__ __forceinline__ void ln_prepare(const GemmParams& p, float* ln_mu, float* ln_rs, int z, int m0, int n0, int tid) {
+    const int cnt = p.ln_swapped ? BN : BM;
+    if (tid >= cnt) return;
+    const bool ok = p.ln_swapped ? (n0 + tid < p.n_valid) : (m0 + tid < p.M);
+    const long long row = p.ln_swapped ? (long long)z * p.ln_zrows + n0 + tid : (long long)m0 + tid;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok) {
+        for (int t = 0; t < p.ln_parts; ++t) {
+            const float* q = p.ln_stat + ((long long)t * p.ln_rows + row) * 2;
+            s1 += q[0];
+            s2 += q[1];
+        }
+    }
+    const float mu = s1 * p.ln_inv_c;
+    ln_mu[tid] = mu;
+    // rows / columns beyond the problem get rstd = 0: their (never stored, or padding) outputs stay finite — a V^T padding column
+    // scaled by rsqrt(eps) could overflow fp16 to inf, and the attention kernel multiplies it by P = 0
+    ln_rs[tid] = ok ? rsqrtf(fmaxf(s2 * p.ln_inv_c - mu * mu, 0.f) + p.ln_eps) : 0.f;
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void ln_apply(const GemmParams& p, f32x4 (&acc)[TM][TN], const float* ln_mu, const float* ln_rs, int m0, int n0, int wm0,
+                                         int wn0, int fr, int fq) {
+    if (!p.ln_swapped) {
+        f32x4 ws[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * 16 + fq * 4;
+            ws[j] = n < p.N ? *reinterpret_cast<const f32x4*>(p.ln_wsum + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float mu = ln_mu[wm0 + i * 16 + fr], rs = ln_rs[wm0 + i * 16 + fr];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (acc[i][j] - mu * ws[j]) * rs;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm0 + i * 16 + fr;
+            const float wsm = m < p.M ? p.ln_wsum[m] : 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x4 mu4 = *reinterpret_cast<const f32x4*>(ln_mu + wn0 + j * 16 + fq * 4);
+                const f32x4 rs4 = *reinterpret_cast<const f32x4*>(ln_rs + wn0 + j * 16 + fq * 4);
+                acc[i][j] = (acc[i][j] - mu4 * wsm) * rs4;
             }
         }
     }
@@ -685,7 +768,9 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
     constexpr int STAGE = (BM + BN) * BK3;
     constexpr int CLD = BN + 8;
     static_assert(BM * CLD <= NST * STAGE, "epilogue tile must fit in the ring");
+    static_assert((BM * CLD * 2 + 15) / 16 * 16 + BM * (BN / 8) * 8 <= NST * STAGE * 2, "LN-fold row statistics must fit behind the epilogue tile");
     __shared__ __attribute__((aligned(16))) half_t smem[NST * STAGE];
+    __shared__ __attribute__((aligned(16))) float ln_mu[BM > BN ? BM : BN], ln_rs[BM > BN ? BM : BN];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -866,6 +951,8 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
     };
 #pragma unroll
     for (int t = 0; t < PF; ++t) issue(kt_begin + t, t);
+    // LN fold: finish (mu, rstd) of this tile's LN rows while the first slabs are in flight (the slab loop's barriers publish it)
+    if (p.ln_stat != nullptr) ln_prepare<BM, BN>(p, ln_mu, ln_rs, z, m0, n0, tid);
     wait_slab(kt_begin);
     __builtin_amdgcn_s_barrier();
     issue(kt_begin + PF, PF);
@@ -914,6 +1001,7 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
         return;
     }
     half_t* Cs = smem;
+    if (p.ln_stat != nullptr) ln_apply<TM, TN>(p, acc, ln_mu, ln_rs, m0, n0, wm0, wn0, fr, fq);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int ml = wm0 + i * 16 + fr;
@@ -927,7 +1015,8 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
         }
     }
     __syncthreads();
-    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid);
+    float* scratch = p.stat_out != nullptr ? reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + (BM * CLD * 2 + 15) / 16 * 16) : nullptr;
+    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid, scratch);
 }
 
 // =====================================================================================================================
@@ -953,6 +1042,7 @@ __global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
     constexpr int CLD = BN + 8;
     static_assert(BM * CLD <= NST * STAGE, "epilogue tile must fit in the ring");
     __shared__ __attribute__((aligned(16))) half_t smem[NST * STAGE];
+    __shared__ __attribute__((aligned(16))) float ln_mu[BM > BN ? BM : BN], ln_rs[BM > BN ? BM : BN];
 
     const int lane = threadIdx.x & 63;
     const int wid8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1106,6 +1196,7 @@ __global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
     }
 
     // ---------------------------------------------------------------------- consumers
+    if (p.ln_stat != nullptr) ln_prepare<BM, BN>(p, ln_mu, ln_rs, z, m0, n0, tid);   // (the slab loop's barriers publish it)
     const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
     const int fr = lane & 15, fq = lane >> 4;
     const half_t* rd0 = smem + (wm0 + fr) * BK3 + ((fq ^ (fr & 7)) << 3);
@@ -1171,6 +1262,7 @@ __global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
         return;
     }
     half_t* Cs = smem;
+    if (p.ln_stat != nullptr) ln_apply<TM, TN>(p, acc, ln_mu, ln_rs, m0, n0, wm0, wn0, fr, fq);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int ml = wm0 + i * 16 + fr;
@@ -1184,7 +1276,8 @@ __global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
         }
     }
     __syncthreads();                                     // consumers only: the producers have exited
-    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid);
+    float* scratch = p.stat_out != nullptr ? reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + (BM * CLD * 2 + 15) / 16 * 16) : nullptr;
+    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid, scratch);
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue
@@ -1310,6 +1403,8 @@ extern "C" void ld_debug_gemm_override(int bm, int splitk) {
     g_force_sk = splitk;
 }
 
+bool gemm_ln_fold_available() { return !use_v1() && v3_min_k() == 1; }
+
 int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     GemmParams p = pin;
     if (g_force_bm) p.bm = g_force_bm;
@@ -1387,6 +1482,11 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         if (p.batch != 1 || p.partial == nullptr) return LD_ERR_ARG;
         while (sk > 1 && (size_t)sk * p.M * p.N * sizeof(float) > p.partial_bytes) --sk;
         if (sk > KT) sk = KT;
+    }
+    if (p.stat_out != nullptr || p.ln_stat != nullptr) {   // LN fold: v3 / v4 kernels, whole K in one workgroup
+        if (!gemm_ln_fold_available() || p.K > 32000 || (p.act == 2 && p.stat_out != nullptr)) return LD_ERR_ARG;
+        sk = 1;
+        if (p.stat_parts_out != nullptr) *p.stat_parts_out = tiles_n;
     }
     p.splitk = sk;
     p.bn = bn;

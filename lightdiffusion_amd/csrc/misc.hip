@@ -342,3 +342,47 @@ int axpby_launch(float* x, float a, const float* y, float b, const float* z, flo
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, stream, x, a, y, b, z, c, n);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm fold (unet.hip): for a projection y = LN(x) W^T + b with LN(x) = (x - mu) * rstd * gamma + beta,
+//   y = rstd * (x W'^T - mu * wsum) + b',   W' = W * diag(gamma),  wsum[n] = sum_k W'[n][k],  b'[n] = b[n] + sum_k W[n][k] * beta[k].
+// One workgroup per weight row, fixed-order tree reduction (bitwise reproducible).  wsum is taken from the fp16-ROUNDED W' so that
+// the subtraction in the consumer's epilogue cancels exactly what the matrix core accumulated.
+namespace {
+__global__ __launch_bounds__(256) void ln_fold_kernel(const half_t* __restrict__ W, int K, const half_t* __restrict__ gamma,
+                                                      const half_t* __restrict__ beta, const half_t* __restrict__ bias, half_t* __restrict__ Wout,
+                                                      half_t* __restrict__ bout, float* __restrict__ wsum) {
+    __shared__ float red[2][256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f, sb = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float w = (float)W[(long long)n * K + k];
+        const half_t wf = (half_t)(w * (float)gamma[k]);
+        Wout[(long long)n * K + k] = wf;
+        s += (float)wf;
+        sb += w * (float)beta[k];
+    }
+    red[0][tid] = s;
+    red[1][tid] = sb;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            red[0][tid] += red[0][tid + o];
+            red[1][tid] += red[1][tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        wsum[n] = red[0][0];
+        bout[n] = (half_t)((bias != nullptr ? (float)bias[n] : 0.f) + red[1][0]);
+    }
+}
+}  // namespace
+
+int ln_fold_launch(const half_t* W, int N, int K, const half_t* gamma, const half_t* beta, const half_t* bias, half_t* Wout, half_t* bout,
+                   float* wsum, hipStream_t stream) {
+    if (W == nullptr || gamma == nullptr || beta == nullptr || Wout == nullptr || bout == nullptr || wsum == nullptr || N <= 0 || K <= 0)
+        return LD_ERR_ARG;
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(N), dim3(256), 0, stream, W, K, gamma, beta, bias, Wout, bout, wsum);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}

@@ -17,6 +17,10 @@ struct ResW {
 };
 struct StW {
     int c = 0, bn = 0, ctx_slot = 0;
+    // LN fold (derived at the first forward after a weight load): gamma-folded weights / beta-folded biases (byte offsets into
+    // ld_unet::fold_base) and their fp32 row sums, for the projections that consume LN1 (q|k, v), LN2 (q of attn2), LN3 (GEGLU)
+    size_t f_qk_w = 0, f_v_w = 0, f_q2_w = 0, f_ff1_w = 0, f_qk_b = 0, f_v_b = 0, f_q2_b = 0, f_ff1_b = 0, f_qk_s = 0, f_v_s = 0, f_q2_s = 0,
+           f_ff1_s = 0;
     int gn_g, gn_b, pin_w, pin_b, ln1_g, ln1_b, q1_w, k1_w, v1_w, o1_w, o1_b, ln2_g, ln2_b, q2_w, k2_w, v2_w, o2_w, o2_b, ln3_g,
         ln3_b, ff1_w, ff1_b, ff2_w, ff2_b, pout_w, pout_b;
 };
@@ -61,6 +65,10 @@ struct ld_unet {
     double last_flops = 0.0;
     Timing timing;
     bool want_timing = false;
+    char* fold_base = nullptr;     // LN-folded copies of the LN-consuming projections (see StW)
+    size_t fold_bytes = 0;
+    bool fold_dirty = true;        // set by every ld_unet_load_param; cleared when the fold kernels have run
+    bool ln_fold = false;          // the GEMM kernels in use implement it (and LD_UNET_NO_LN_FOLD is not set)
 };
 
 namespace {
@@ -129,6 +137,27 @@ int add_st(ld_unet* u, const std::string& p, int c) {
     s.ff2_b = t.add(b + ".ff.net.2.bias", PK_VEC, {c});
     s.pout_w = t.add(p + ".proj_out.weight", PK_MAT, {c, c, 1, 1});
     s.pout_b = t.add(p + ".proj_out.bias", PK_VEC, {c});
+    {   // LN-fold buffer layout (256-byte aligned pieces)
+        size_t& fb = u->fold_bytes;
+        auto take = [&](size_t bytes) {
+            const size_t o = fb;
+            fb += (bytes + 255) / 256 * 256;
+            return o;
+        };
+        const size_t C = (size_t)c;
+        s.f_qk_w = take(2 * C * C * sizeof(half_t));
+        s.f_v_w = take(C * C * sizeof(half_t));
+        s.f_q2_w = take(C * C * sizeof(half_t));
+        s.f_ff1_w = take(8 * C * C * sizeof(half_t));
+        s.f_qk_b = take(2 * C * sizeof(half_t));
+        s.f_v_b = take(C * sizeof(half_t));
+        s.f_q2_b = take(C * sizeof(half_t));
+        s.f_ff1_b = take(8 * C * sizeof(half_t));
+        s.f_qk_s = take(2 * C * sizeof(float));
+        s.f_v_s = take(C * sizeof(float));
+        s.f_q2_s = take(C * sizeof(float));
+        s.f_ff1_s = take(8 * C * sizeof(float));
+    }
     u->st.push_back(s);
     return (int)u->st.size() - 1;
 }
@@ -283,23 +312,67 @@ struct Run {
         half_t* g = ar.halfs((size_t)M * C);
         ex.groupnorm(x, C, nullptr, 0, n, L, P(s.gn_g), P(s.gn_b), 1e-6f, 0, g);
         half_t* t = ar.halfs((size_t)M * C);
-        linear(g, C, s.pin_w, s.pin_b, nullptr, t, M, C, C);
-        half_t* nrm = g;   // reuse
-        // ---- self attention: x += to_out(attn(LN1(x)))
-        ex.layernorm(t, P(s.ln1_g), P(s.ln1_b), nrm, M, C);
-        half_t* qk = ar.halfs((size_t)M * 2 * C);
-        linear(nrm, C, s.q1_w, -1, nullptr, qk, M, 2 * C, C);
         const int Lp = (L + 7) & ~7;   // V^T rows are padded to 8 keys (16-byte row copies in the attention kernel)
+        half_t* nrm = g;               // reuse (only the un-folded path materialises LN(x))
+        half_t* qk = ar.halfs((size_t)M * 2 * C);
         half_t* vt = ar.halfs((size_t)n * C * Lp);
-        {   // V^T[b] = Wv · LN(x)_b^T  -> [C][Lp] per sample (swapped GEMM: the weight is the row operand)
+        half_t* ao = ar.halfs((size_t)M * C);
+        half_t* ff = nullptr;
+        const bool fold = u->ln_fold;
+        // LN fold: the three LayerNorms disappear into the GEMMs around them.  The GEMM that WRITES the residual stream t also
+        // writes per-row (sum, sum of squares) partials of t (one pair per N tile); the projections that read LN(t) run on t itself
+        // with gamma folded into their weights and finish  rstd * (acc - mu * wsum) + b'  in the epilogue (gemm.h).
+        float* stat = fold ? reinterpret_cast<float*>(ar.alloc((size_t)((C + 63) / 64) * M * 2 * sizeof(float))) : nullptr;
+        int parts = 0;
+        char* fb = u->fold_base;
+        auto producer = [&](const half_t* x_, int lda, int wslot, int bslot, const half_t* R, int K) {   // t = x_ W^T + b (+ R), with row stats
             GemmParams p;
-            p.A = P(s.v1_w); p.lda = C; p.sA = 0;
-            p.W = nrm; p.ldw = C; p.sW = (long long)L * C;
-            p.M = C; p.N = Lp; p.n_valid = L; p.K = C; p.batch = n;
-            p.C = vt; p.ldc = Lp; p.sC = (long long)C * Lp;
+            p.A = x_; p.lda = lda;
+            p.W = P(wslot); p.ldw = K;
+            p.M = M; p.N = C; p.K = K;
+            p.bias_n = P(bslot);
+            p.R = R; p.ldr = C;
+            p.C = t; p.ldc = C;
+            if (fold) {
+                p.stat_out = stat;
+                p.stat_parts_out = &parts;
+            }
+            ex.gemm(p);
+        };
+        auto ln_args = [&](GemmParams& p, size_t wsum_off) {
+            p.ln_stat = stat; p.ln_parts = parts; p.ln_rows = M;
+            p.ln_inv_c = 1.0f / (float)C; p.ln_eps = 1e-5f;
+            p.ln_wsum = reinterpret_cast<const float*>(fb + wsum_off);
+        };
+        producer(g, C, s.pin_w, s.pin_b, nullptr, C);
+        // ---- self attention: x += to_out(attn(LN1(x)))
+        if (!fold) ex.layernorm(t, P(s.ln1_g), P(s.ln1_b), nrm, M, C);
+        {   // [q | k] = LN1(t) [Wq ; Wk]^T
+            GemmParams p;
+            p.A = fold ? t : nrm; p.lda = C;
+            p.W = fold ? reinterpret_cast<const half_t*>(fb + s.f_qk_w) : P(s.q1_w); p.ldw = C;
+            p.M = M; p.N = 2 * C; p.K = C;
+            p.C = qk; p.ldc = 2 * C;
+            if (fold) {
+                p.bias_n = reinterpret_cast<const half_t*>(fb + s.f_qk_b);
+                ln_args(p, s.f_qk_s);
+            }
             ex.gemm(p);
         }
-        half_t* ao = ar.halfs((size_t)M * C);
+        {   // V^T[b] = Wv · LN1(t)_b^T  -> [C][Lp] per sample (swapped GEMM: the weight is the row operand)
+            GemmParams p;
+            p.A = fold ? reinterpret_cast<const half_t*>(fb + s.f_v_w) : P(s.v1_w); p.lda = C; p.sA = 0;
+            p.W = fold ? t : nrm; p.ldw = C; p.sW = (long long)L * C;
+            p.M = C; p.N = Lp; p.n_valid = L; p.K = C; p.batch = n;
+            p.C = vt; p.ldc = Lp; p.sC = (long long)C * Lp;
+            if (fold) {
+                p.bias_m = reinterpret_cast<const half_t*>(fb + s.f_v_b);
+                ln_args(p, s.f_v_s);
+                p.ln_swapped = 1;
+                p.ln_zrows = L;
+            }
+            ex.gemm(p);
+        }
         {
             AttnParams a;
             a.Q = qk; a.ldq = 2 * C; a.sQ = (long long)L * 2 * C;
@@ -310,11 +383,22 @@ struct Run {
             a.scale = 1.0f / sqrtf((float)d);
             ex.attention(a);
         }
-        linear(ao, C, s.o1_w, s.o1_b, t, t, M, C, C);
+        producer(ao, C, s.o1_w, s.o1_b, t, C);
         // ---- cross attention against the hoisted context K / V^T
-        ex.layernorm(t, P(s.ln2_g), P(s.ln2_b), nrm, M, C);
+        if (!fold) ex.layernorm(t, P(s.ln2_g), P(s.ln2_b), nrm, M, C);
         half_t* q2 = qk;   // reuse
-        linear(nrm, C, s.q2_w, -1, nullptr, q2, M, C, C);
+        {
+            GemmParams p;
+            p.A = fold ? t : nrm; p.lda = C;
+            p.W = fold ? reinterpret_cast<const half_t*>(fb + s.f_q2_w) : P(s.q2_w); p.ldw = C;
+            p.M = M; p.N = C; p.K = C;
+            p.C = q2; p.ldc = C;
+            if (fold) {
+                p.bias_n = reinterpret_cast<const half_t*>(fb + s.f_q2_b);
+                ln_args(p, s.f_q2_s);
+            }
+            ex.gemm(p);
+        }
         {
             const int Tp = u->ctx_tpad;
             AttnParams a;
@@ -326,11 +410,21 @@ struct Run {
             a.scale = 1.0f / sqrtf((float)d);
             ex.attention(a);
         }
-        linear(ao, C, s.o2_w, s.o2_b, t, t, M, C, C);
+        producer(ao, C, s.o2_w, s.o2_b, t, C);
         // ---- GEGLU feed-forward: x = ff2(a * gelu(gate)) + x
-        ex.layernorm(t, P(s.ln3_g), P(s.ln3_b), nrm, M, C);
-        half_t* ff = ar.halfs((size_t)M * 4 * C);
-        linear(nrm, C, s.ff1_w, s.ff1_b, nullptr, ff, M, 8 * C, C, 2, s.bn);
+        if (!fold) ex.layernorm(t, P(s.ln3_g), P(s.ln3_b), nrm, M, C);
+        ff = ar.halfs((size_t)M * 4 * C);
+        {
+            GemmParams p;
+            p.A = fold ? t : nrm; p.lda = C;
+            p.W = fold ? reinterpret_cast<const half_t*>(fb + s.f_ff1_w) : P(s.ff1_w); p.ldw = C;
+            p.M = M; p.N = 8 * C; p.K = C;
+            p.bias_n = fold ? reinterpret_cast<const half_t*>(fb + s.f_ff1_b) : P(s.ff1_b);
+            p.act = 2; p.bn = s.bn;
+            p.C = ff; p.ldc = 4 * C; p.ldr = 4 * C;
+            if (fold) ln_args(p, s.f_ff1_s);
+            ex.gemm(p);
+        }
         linear(ff, 4 * C, s.ff2_w, s.ff2_b, t, t, M, C, 4 * C);
         linear(t, C, s.pout_w, s.pout_b, x, out, M, C, C);
         ar.release(mk);
@@ -338,8 +432,31 @@ struct Run {
     }
 };
 
+// LN fold: derive W' = W diag(gamma), b' = b + W beta and the fp32 row sums of W' for the projections that read LN1 / LN2 / LN3
+// (64 small launches, once per weight load; stream-ordered before the forward that needs them).
+int fold_layernorms(ld_unet* u, hipStream_t stream) {
+    for (const StW& s : u->st) {
+        const int C = s.c;
+        char* fb = u->fold_base;
+        auto H = [&](size_t off) { return reinterpret_cast<half_t*>(fb + off); };
+        auto F = [&](size_t off) { return reinterpret_cast<float*>(fb + off); };
+        const half_t* P_q1 = u->pt.ptr(s.q1_w);   // to_q and to_k are contiguous: one [2C][C] matrix
+        int st = ln_fold_launch(P_q1, 2 * C, C, u->pt.ptr(s.ln1_g), u->pt.ptr(s.ln1_b), nullptr, H(s.f_qk_w), H(s.f_qk_b), F(s.f_qk_s), stream);
+        if (st == LD_OK) st = ln_fold_launch(u->pt.ptr(s.v1_w), C, C, u->pt.ptr(s.ln1_g), u->pt.ptr(s.ln1_b), nullptr, H(s.f_v_w), H(s.f_v_b), F(s.f_v_s), stream);
+        if (st == LD_OK) st = ln_fold_launch(u->pt.ptr(s.q2_w), C, C, u->pt.ptr(s.ln2_g), u->pt.ptr(s.ln2_b), nullptr, H(s.f_q2_w), H(s.f_q2_b), F(s.f_q2_s), stream);
+        if (st == LD_OK) st = ln_fold_launch(u->pt.ptr(s.ff1_w), 8 * C, C, u->pt.ptr(s.ln3_g), u->pt.ptr(s.ln3_b), u->pt.ptr(s.ff1_b), H(s.f_ff1_w), H(s.f_ff1_b), F(s.f_ff1_s), stream);
+        if (st != LD_OK) return st;
+    }
+    u->fold_dirty = false;
+    return LD_OK;
+}
+
 int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, hipStream_t stream,
                 size_t* dry_peak = nullptr) {
+    if (!dry && u->ln_fold && u->fold_dirty) {
+        const int st = fold_layernorms(u, stream);
+        if (st != LD_OK) return st;
+    }
     Run R;
     R.u = u;
     R.n = n;
@@ -479,6 +596,13 @@ int ld_unet_create(const ld_unet_config* cfg, ld_unet** out) {
             ls[i] = (float)log(sqrt((1.0 - ac) / ac));
         }
     }
+    static const bool no_fold = getenv("LD_UNET_NO_LN_FOLD") != nullptr;   // A/B knob: keep the stand-alone LayerNorm launches
+    u->ln_fold = !no_fold && gemm_ln_fold_available();
+    if (u->ln_fold && u->fold_bytes > 0 && hipMalloc((void**)&u->fold_base, u->fold_bytes) != hipSuccess) {
+        u->pt.destroy();
+        delete u;
+        return LD_ERR_HIP;
+    }
     if (hipMalloc((void**)&u->log_sigmas, 1000 * sizeof(float)) != hipSuccess ||
         hipMemcpy(u->log_sigmas, ls.data(), 1000 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         u->pt.destroy();
@@ -495,6 +619,7 @@ void ld_unet_destroy(ld_unet* u) {
     u->timing.destroy();
     if (u->ws_base) (void)hipFree(u->ws_base);
     if (u->log_sigmas) (void)hipFree(u->log_sigmas);
+    if (u->fold_base) (void)hipFree(u->fold_base);
     delete u;
 }
 
@@ -512,11 +637,12 @@ int ld_unet_param_info(const ld_unet* u, int i, const char** name, int* ndim, in
 
 int ld_unet_load_param(ld_unet* u, const char* name, const void* src, int dtype, void* stream) {
     if (u == nullptr || name == nullptr) return LD_ERR_ARG;
+    u->fold_dirty = true;   // the LN-folded copies are re-derived at the next forward
     return u->pt.load(name, src, dtype, (hipStream_t)stream);
 }
 
 size_t ld_unet_workspace_bytes(const ld_unet* u) { return u ? u->ws_bytes : 0; }
-size_t ld_unet_weight_bytes(const ld_unet* u) { return u ? u->pt.bytes : 0; }
+size_t ld_unet_weight_bytes(const ld_unet* u) { return u ? u->pt.bytes + (u->fold_base ? u->fold_bytes : 0) : 0; }
 
 int ld_unet_reserve(ld_unet* u, int max_n, int max_h, int max_w, int max_tok) {
     if (u == nullptr || max_n < 1 || max_h < 1 || max_w < 1 || max_tok < 1) return LD_ERR_ARG;
