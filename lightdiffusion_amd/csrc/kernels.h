@@ -9,9 +9,10 @@
 // pixel chunks per image: aim at ~2048 blocks (x 4 channel slabs x n images), at least 8 pixels per chunk, at most 256 chunks
 static inline int gn_num_chunks(int n_img, int HW) {
     // workgroups per launch, measured (profiles/README.md): 512 is best at UNet batch 2 (GroupNorm 0.92 -> 0.74 ms per forward),
-    // 1024 at UNet batch 16 (1.51 -> 1.40 ms); LD_GN_BLOCKS overrides (A/B knob)
+    // 1024 at UNet batch 16 (1.51 -> 1.40 ms), 2048 for the 512x512 VAE tensors; LD_GN_BLOCKS overrides (A/B knob)
     static const int env_target = getenv("LD_GN_BLOCKS") ? atoi(getenv("LD_GN_BLOCKS")) : 0;
-    const int target = env_target ? env_target : (n_img <= 4 ? 512 : 1024);
+    const long long px = (long long)(n_img < 1 ? 1 : n_img) * HW;   // (sized by pixels: a batch-1 VAE image is one huge tensor)
+    const int target = env_target ? env_target : (px <= 8192 ? 512 : (px <= 131072 ? 1024 : 2048));
     int p = target / (4 * (n_img < 1 ? 1 : n_img));
     if (p > HW / 8) p = HW / 8;
     if (p > 256) p = 256;
