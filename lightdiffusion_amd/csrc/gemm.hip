@@ -1326,6 +1326,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     }
 }
 
+int v4_max_blocks() {   // plain GEMMs with at most this many workgroups take the producer/consumer kernel; LD_GEMM_V4_MAX overrides (A/B knob)
+    static const int v = getenv("LD_GEMM_V4_MAX") ? atoi(getenv("LD_GEMM_V4_MAX")) : 256;
+    return v;
+}
 bool use_v1() {
     static const bool v = getenv("LD_GEMM_V1") != nullptr;
     return v;
@@ -1342,7 +1346,7 @@ void launch_cfg_v34(const GemmParams& p, hipStream_t s) {   // tile shapes that 
     const int sk = p.splitk > 1 ? p.splitk : 1;
     dim3 grid(tiles * sk, 1, p.batch);
     static const int env_v4 = getenv("LD_GEMM_V4") ? atoi(getenv("LD_GEMM_V4")) : -1;
-    if (env_v4 == 1 || (env_v4 < 0 && !p.conv && (long long)tiles * sk * p.batch <= 256)) {
+    if (env_v4 == 1 || (env_v4 < 0 && !p.conv && (long long)tiles * sk * p.batch <= v4_max_blocks())) {
         if (p.conv) hipLaunchKernelGGL((gemm4_kernel<BM, BN, true>), grid, dim3(2 * NT), 0, s, p);
         else hipLaunchKernelGGL((gemm4_kernel<BM, BN, false>), grid, dim3(2 * NT), 0, s, p);
     } else {
@@ -1365,7 +1369,7 @@ void launch_cfg(const GemmParams& p, hipStream_t s) {
         // producer/consumer kernel: wins where a plain GEMM leaves at most one workgroup per CU (batch-1 step: +5.6 % whole
         // step, same box A/B); loses on convs and wherever two v3 workgroups share a CU.  LD_GEMM_V4 = 0 never, 1 always.
         static const int env_v4 = getenv("LD_GEMM_V4") ? atoi(getenv("LD_GEMM_V4")) : -1;
-        if (env_v4 == 1 || (env_v4 < 0 && !p.conv && (long long)tiles * sk * p.batch <= 256)) {
+        if (env_v4 == 1 || (env_v4 < 0 && !p.conv && (long long)tiles * sk * p.batch <= v4_max_blocks())) {
             dim3 block8(2 * NT);
             if (p.conv)
                 hipLaunchKernelGGL((gemm4_kernel<BM, BN, true>), grid, block8, 0, s, p);
