@@ -1326,10 +1326,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     }
 }
 
-int v4_max_blocks() {   // plain GEMMs with at most this many workgroups take the producer/consumer kernel; LD_GEMM_V4_MAX overrides (A/B knob)
-    static const int v = getenv("LD_GEMM_V4_MAX") ? atoi(getenv("LD_GEMM_V4_MAX")) : 256;
-    return v;
-}
 int v4_max_blocks() {   // plain GEMMs with at most this many workgroups take the producer/consumer kernel (measured at B=1: 256 -> 169.3,
     // 512 -> 167.8, 768 -> 166.2, 1280 -> 164.8 steps/s); LD_GEMM_V4_MAX overrides (A/B knob)
     static const int v = getenv("LD_GEMM_V4_MAX") ? atoi(getenv("LD_GEMM_V4_MAX")) : 256;
