@@ -1,6 +1,9 @@
 // Flash-style attention for the UNet's self / cross attention (softmax(QK^T/sqrt(d)) V, no mask — LD.py:3966-3978).
 //
-// gfx950 design (32x32x16 f16 MFMA, wave = 64):
+// Two kernels: flash_attn2_kernel (further down; the one launched) and flash_attn_kernel (the first version, kept for A/B under
+// LD_ATTN_V1=1).  They share the register-level design; what differs is the tile pipeline and the softmax bookkeeping.
+//
+// gfx950 design (32x32x16 f16 MFMA, wave = 64) — flash_attn_kernel:
 //  * one workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.
 //  * S^T = K·Q^T ("swapped" product): the query sits on the MFMA lane, so a lane's 16 accumulator registers are
 //    16 keys of ONE query and the online softmax needs no cross-lane traffic except one half-wave exchange.
@@ -15,6 +18,8 @@
 #include <cstdlib>
 
 #include "kernels.h"
+// Ablation builds behind profiles/README.md ("no exp", "no tile sync", "1 of 4 PV MFMAs", "2 of 7 fragment reads"): -DLD_ATT_DBG=1..4.
+// They compute WRONG results on purpose (timing only) and are never part of the shipped library.
 #ifndef LD_ATT_DBG
 #define LD_ATT_DBG 0
 #endif

@@ -13,6 +13,8 @@
 #include <type_traits>
 
 #include "gemm.h"
+// Ablation build behind profiles/README.md: -DLD_DBG=6 makes every workgroup stream the SAME tile (all loads hit cache; wrong results,
+// timing only).  Never part of the shipped library.
 #ifndef LD_DBG
 #define LD_DBG 0
 #endif

@@ -2,7 +2,7 @@
 
 One sampler step of the reference = `sampling_function` (LD.py:2609-2626): cat([x, x]) → UNet on N = 2B samples in
 the order [uncond, cond] → uncond + (cond - uncond) * cfg.  Here the 2B-sample input, sigma and output live in static
-device buffers, the ~300 kernel launches of the forward plus the guidance mix are captured once into a hipGraph and
+device buffers, the ~370 kernel launches of the forward plus the guidance mix are captured once into a hipGraph and
 replayed per step (sigma is read from device memory, so one graph serves every step).
 """
 from __future__ import annotations
