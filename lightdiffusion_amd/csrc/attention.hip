@@ -16,6 +16,7 @@
 //  * O rescale is skipped (wave-uniform branch) whenever no running max moved — exact, not thresholded.
 // Head dims: d % 8 == 0, d <= 160 (SD1.5: 40 / 80 / 160).  Template DK = ceil(d/16) k-steps of QK^T.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 // Ablation builds behind profiles/README.md ("no exp", "no tile sync", "1 of 4 PV MFMAs", "2 of 7 fragment reads"): -DLD_ATT_DBG=1..4.
@@ -375,9 +376,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
     // ---- fragment read offsets (halfs, relative to the K tile / V^T tile of a buffer)
     const int prow = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);   // bit-2 <-> bit-3 row permutation (see header)
     const int ksw = (prow >> sw_shift) & sw_mask;                   // same for row + 32: only row bits < 3 enter
-    int koff[DK];
+    // (K offsets are kept per 32-key half of the tile while that is cheap, so that with the buffer index a literal (the tile loop
+    // is unrolled over the two buffers) every fragment read is one ds_read with an immediate offset and no address arithmetic)
+    constexpr int KSUB = DK <= 4 ? 2 : 1;   // (only the kernels that unroll the tile loop profit)
+    int koff[KSUB][DK];
 #pragma unroll
-    for (int ks = 0; ks < DK; ++ks) koff[ks] = (prow * dch + ((2 * ks + hh) ^ ksw)) << 3;
+    for (int h = 0; h < KSUB; ++h)
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) koff[h][ks] = ((h * 32 + prow) * dch + ((2 * ks + hh) ^ ksw)) << 3;
     int voff[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) voff[c] = TILE_CH * 8 + ((r * 8 + ((2 * c + hh) ^ (r & 7))) << 3);   // c = 2*sub + k2
@@ -402,12 +408,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
     // for them at the first MFMA inside the loop, where it also drains the next tile's in-flight LDS-DMA every iteration.
     __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0), expcnt/lgkmcnt untouched
     issue(0, 0);
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile = [&](int t, auto bufc) {
+        const int BUF = static_cast<int>(bufc);   // a literal when the caller passes an integral_constant (folds after inlining)
         const int key0 = t * KT;
         wait_vmcnt<0>();                   // this wave's share of tile t has landed ...
         __builtin_amdgcn_s_barrier();      // ... everyone's has, and nobody still reads tile t-1's buffer
-        if (t + 1 < ntiles) issue(key0 + KT, (t + 1) & 1);
-        const half_t* T = smem + (t & 1) * BUF_H;
+        if (t + 1 < ntiles) issue(key0 + KT, BUF ^ 1);
+        const half_t* T = smem + BUF * BUF_H;
         // S^T of one 32-key subtile, already relative to the softmax reference: -m_ref is the C operand of the first k-step.
         // That first MFMA is written in asm: D (early-clobber) != C pins the three-address form, so -m_ref is read in place;
         // through the builtin hipcc ties D to C and copies the 16 reference registers.  (Hazards: the next reader of s is the
@@ -417,9 +424,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
 #pragma unroll
             for (int ks = 0; ks < DK; ++ks) {
 #if LD_ATT_DBG == 4
-                const half8 kf = as_half8(ld16(T + sub * 32 * d + koff[0]));
+                const half8 kf = as_half8(ld16(T + (KSUB == 2 ? koff[sub & (KSUB - 1)][0] : sub * 32 * d + koff[0][0])));
 #else
-                const half8 kf = as_half8(ld16(T + sub * 32 * d + koff[ks]));
+                const half8 kf = as_half8(ld16(T + (KSUB == 2 ? koff[sub & (KSUB - 1)][ks] : sub * 32 * d + koff[0][ks])));
 #endif
                 if (ks == 0 && DK == 1) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], negm, 0, 0, 0);
                 else if (ks == 0) asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s) : "v"(kf), "v"(qf[0]), "v"(negm));
@@ -520,6 +527,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
                 finish(sub, s, nullptr, t == 0 && sub == 0);
             }
         }
+    };
+    if (DK <= 4) {   // small heads: unroll over the two buffers (d=40: -4 % at L=4096 / 16384); d=80 is flat, d=160 loses registers
+        for (int t = 0; t < ntiles; t += 2) {
+            tile(t, std::integral_constant<int, 0>{});
+            if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (int t = 0; t < ntiles; ++t) tile(t, t & 1);
     }
 
     float l_tot;
