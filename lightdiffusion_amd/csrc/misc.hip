@@ -81,48 +81,85 @@ __global__ __launch_bounds__(256) void small_conv_in_kernel(const SmallConvInArg
 }
 
 // ------------------------------------------------------------------------------------------------ conv_out
-// 3x3 pad-1 conv to Cout <= 4 channels from NHWC fp16: one wave per output pixel, lanes stride over the 9*Cin
-// reduction in 16-byte chunks, wave-shuffle reduction.  Fused boundary math per `mode`.
+// 3x3 pad-1 conv to Cout <= 4 channels from NHWC fp16.  One wave per output pixel at a time; the 9*Cin reduction is split into
+// 16-byte chunks and every lane OWNS the same chunks (tap, 8 channels) for all the pixels its wave visits, so the weights of
+// those chunks live in registers for the whole kernel (the first version re-read 4 weight chunks per input chunk per pixel: 29 KB of
+// cache traffic per pixel, 263 us for the 512x512 VAE output conv).  All input chunks of a pixel are loaded before the first
+// FMA; wave-shuffle reduction; fused boundary math per `mode`.
+// NCH = owned chunks per lane (9 * Cin / 8 / 64 rounded up), PX = pixels a wave works on at once (loads of all of them in flight).
+template <int NCH, int PX>
 __global__ __launch_bounds__(256) void small_conv_out_kernel(const SmallConvOutArgs a) {
     const int lane = threadIdx.x & 63;
     const long long npix = (long long)a.N * a.H * a.W;
     const int CH = a.Cin >> 3;           // chunks per tap
     const int KK = 9 * a.Cin;
-    for (long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (long long)gridDim.x * 4) {
-        const int x = (int)(pix % a.W);
-        const int y = (int)((pix / a.W) % a.H);
-        const int n = (int)(pix / ((long long)a.W * a.H));
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = lane; c < 9 * CH; c += 64) {
-            const int tap = c / CH, cc = c - tap * CH;
-            const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
-            if ((unsigned)iy >= (unsigned)a.H || (unsigned)ix >= (unsigned)a.W) continue;
-            float v[8];
-            unpack8(ld16(a.x + (((long long)n * a.H + iy) * a.W + ix) * a.Cin + cc * 8), v);
-            for (int o = 0; o < a.Cout; ++o) {
-                float w[8];
-                unpack8(ld16(a.w + (long long)o * KK + tap * a.Cin + cc * 8), w);
+    const int total = 9 * CH;
+    int dy[NCH], dx[NCH], co[NCH];
+    uint4 wv[NCH][4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[o] += v[j] * w[j];
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + i * 64;
+        const bool own = c < total;
+        const int tap = own ? c / CH : 0, cc = own ? c - tap * CH : 0;
+        dy[i] = tap / 3 - 1;
+        dx[i] = tap % 3 - 1;
+        co[i] = own ? cc * 8 : -1;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            wv[i][o] = (own && o < a.Cout) ? ld16(a.w + (long long)o * KK + tap * a.Cin + cc * 8) : zero16();
+    }
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    for (long long pix0 = wave * PX; pix0 < npix; pix0 += nwaves * PX) {
+        uint4 xv[PX][NCH];
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            const long long pix = pix0 + q;
+            const int x = (int)(pix % a.W);
+            const int y = (int)((pix / a.W) % a.H);
+            const int n = (int)(pix / ((long long)a.W * a.H));
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int iy = y + dy[i], ix = x + dx[i];
+                const bool ok = pix < npix && co[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                xv[q][i] = ok ? ld16(a.x + (((long long)n * a.H + iy) * a.W + ix) * a.Cin + co[i]) : zero16();
             }
         }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) acc[o] = wave_sum(acc[o]);
-        if (lane < a.Cout) {
-            const int o = lane;
-            float v = acc[0];
-            if (o == 1) v = acc[1];
-            if (o == 2) v = acc[2];
-            if (o == 3) v = acc[3];
-            v += (float)a.b[o];
-            const long long nchw = (((long long)n * a.Cout + o) * a.H + y) * a.W + x;
-            if (a.mode == 0) {
-                const float eps = (float)(half_t)v;   // the reference's UNet output is an fp16 tensor (.float() after)
-                a.out[nchw] = a.x_in[nchw] - eps * a.sigma[n];
-            } else if (a.mode == 1) {
-                a.out[pix * a.Cout + o] = fminf(fmaxf((v + 1.0f) * 0.5f, 0.f), 1.f);
-            } else {
-                a.out[nchw] = v;
+        for (int q = 0; q < PX; ++q) {
+            const long long pix = pix0 + q;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {   // packed fp16 pairs, fp32 accumulate (v_dot2_f32_f16): weights stay packed in registers
+                const unsigned xs[4] = {xv[q][i].x, xv[q][i].y, xv[q][i].z, xv[q][i].w};
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const unsigned ws[4] = {wv[i][o].x, wv[i][o].y, wv[i][o].z, wv[i][o].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[o] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, xs[j]), __builtin_bit_cast(half2v, ws[j]), acc[o], false);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o] = wave_sum(acc[o]);
+            if (lane < a.Cout && pix < npix) {
+                const int x = (int)(pix % a.W);
+                const int y = (int)((pix / a.W) % a.H);
+                const int n = (int)(pix / ((long long)a.W * a.H));
+                const int o = lane;
+                float v = acc[0];
+                if (o == 1) v = acc[1];
+                if (o == 2) v = acc[2];
+                if (o == 3) v = acc[3];
+                v += (float)a.b[o];
+                const long long nchw = (((long long)n * a.Cout + o) * a.H + y) * a.W + x;
+                if (a.mode == 0) {
+                    const float eps = (float)(half_t)v;   // the reference's UNet output is an fp16 tensor (.float() after)
+                    a.out[nchw] = a.x_in[nchw] - eps * a.sigma[n];
+                } else if (a.mode == 1) {
+                    a.out[pix * a.Cout + o] = fminf(fmaxf((v + 1.0f) * 0.5f, 0.f), 1.f);
+                } else {
+                    a.out[nchw] = v;
+                }
             }
         }
     }
@@ -275,8 +312,16 @@ int small_conv_out_launch(const SmallConvOutArgs& a, hipStream_t stream) {
     if (a.x == nullptr || a.w == nullptr || a.b == nullptr || a.out == nullptr) return LD_ERR_ARG;
     if (a.Cout < 1 || a.Cout > 4 || (a.Cin & 7)) return LD_ERR_SHAPE;
     if (a.mode == 0 && (a.x_in == nullptr || a.sigma == nullptr)) return LD_ERR_ARG;
+    const int nch = (9 * (a.Cin >> 3) + 63) / 64;        // chunks a lane owns
+    if (nch > 9) return LD_ERR_SHAPE;                    // Cin <= 512
     const long long npix = (long long)a.N * a.H * a.W;
-    hipLaunchKernelGGL(small_conv_out_kernel, dim3(grid_for(npix, 4, 8192)), dim3(256), 0, stream, a);
+    long long waves = npix / 16;                         // >= 16 pixels per wave amortise the weight preload
+    if (waves > 8192) waves = 8192;
+    if (waves < 4) waves = 4;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+    if (nch <= 3) hipLaunchKernelGGL((small_conv_out_kernel<3, 4>), grid, block, 0, stream, a);
+    else if (nch <= 6) hipLaunchKernelGGL((small_conv_out_kernel<6, 2>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((small_conv_out_kernel<9, 1>), grid, block, 0, stream, a);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
 
