@@ -343,10 +343,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
 #pragma unroll
     for (int i = 0; i < LIT; ++i) {
         const int q = tid + i * NT2;
+        // LDS row `row` holds key perm(row) (bits 2 and 3 swapped): the MFMA operand trick wants lane r to read key perm(r), and
+        // with the permutation applied HERE lane r reads LDS row r — 8 consecutive lanes then hit 8 distinct 16-byte slots
+        // (reading rows 0-3, 8-11 of an 80-byte-stride tile instead put lanes 4-7 on the banks of lanes 0-3: 36 % of the LDS-active
+        // cycles were bank conflicts, profiles/r01_f_attention_pmc.csv)
         const int row = q / dch, cph = q - row * dch;
-        krow[i] = row;
+        const int key = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);
+        krow[i] = key;
         kval[i] = row < KT;
-        kp[i] = kval[i] ? Kg + (long long)row * p.ldk + ((cph ^ ((row >> sw_shift) & sw_mask)) << 3) : zp;
+        kp[i] = kval[i] ? Kg + (long long)key * p.ldk + ((cph ^ ((row >> sw_shift) & sw_mask)) << 3) : zp;
         const int vr = q >> 3, vc = (q & 7) ^ (vr & 7);
         vkey[i] = vc << 3;
         vdat[i] = vr < d;
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
     };
 
     // ---- fragment read offsets (halfs, relative to the K tile / V^T tile of a buffer)
-    const int prow = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);   // bit-2 <-> bit-3 row permutation (see header)
+    const int prow = r;                                             // (the bit-2 <-> bit-3 key permutation is applied by the loader)
     const int ksw = (prow >> sw_shift) & sw_mask;                   // same for row + 32: only row bits < 3 enter
     // (K offsets are kept per 32-key half of the tile while that is cheap, so that with the buffer index a literal (the tile loop
     // is unrolled over the two buffers) every fragment read is one ds_read with an immediate offset and no address arithmetic)
