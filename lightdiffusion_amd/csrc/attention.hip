@@ -344,9 +344,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
     for (int i = 0; i < LIT; ++i) {
         const int q = tid + i * NT2;
         // LDS row `row` holds key perm(row) (bits 2 and 3 swapped): the MFMA operand trick wants lane r to read key perm(r), and
-        // with the permutation applied HERE lane r reads LDS row r — 8 consecutive lanes then hit 8 distinct 16-byte slots
-        // (reading rows 0-3, 8-11 of an 80-byte-stride tile instead put lanes 4-7 on the banks of lanes 0-3: 36 % of the LDS-active
-        // cycles were bank conflicts, profiles/r01_f_attention_pmc.csv)
+        // with the permutation applied HERE lane r simply reads LDS row r (consecutive lanes, consecutive rows; measured 2-5 % faster
+        // than permuting at read time, profiles/README.md)
         const int row = q / dch, cph = q - row * dch;
         const int key = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);
         krow[i] = key;
@@ -428,7 +427,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
         auto qk = [&](int sub, f32x16& s) {
 #pragma unroll
             for (int ks = 0; ks < DK; ++ks) {
-#if LD_ATT_DBG == 4
+#if LD_ATT_DBG == 5
+                const half8 kf = qf[ks];
+#elif LD_ATT_DBG == 4
                 const half8 kf = as_half8(ld16(T + (KSUB == 2 ? koff[sub & (KSUB - 1)][0] : sub * 32 * d + koff[0][0])));
 #else
                 const half8 kf = as_half8(ld16(T + (KSUB == 2 ? koff[sub & (KSUB - 1)][ks] : sub * 32 * d + koff[0][ks])));
@@ -513,7 +514,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
             for (int tt = 0; tt < DV; ++tt)
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
-#if LD_ATT_DBG == 4
+#if LD_ATT_DBG == 6
+                    const half8 vf = pf[k2];
+#elif LD_ATT_DBG == 4
                     const half8 vf = as_half8(ld16(T + voff[2 * sub]));
 #else
                     const half8 vf = as_half8(ld16(T + tt * 32 * 64 + voff[2 * sub + k2]));
