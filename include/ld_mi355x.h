@@ -130,6 +130,16 @@ int ld_op_timestep_embed(const float* sigma, const float* log_sigmas, int n_sigm
 int ld_op_cfg_combine(const float* den2, float* out, float cfg, size_t n_half, void* stream);
 int ld_op_axpby(float* x, float a, const float* y, float b, const float* z, float c, size_t n, void* stream);
 
+/* The LayerNorm fold of the UNet's transformer blocks (BasicTransformerBlock, LD.py:4117-4162: every attention / GEGLU
+ * projection reads LayerNorm(x)) as an operator pair, for parity tests: t[M][C] = x · w_prod^T + b_prod (the GEMM that writes the
+ * residual stream, emitting per-row statistics) and y[M][N] = LayerNorm(t; gamma, beta, eps) · w^T + bias, finished on the fp32
+ * accumulators of t · (w diag(gamma))^T.  ws: >= 2*N*C + 8*N + 8*((C+63)/64)*M + 1024 bytes. */
+int ld_op_linear_ln(const void* x, const void* w_prod, const void* b_prod, const void* gamma, const void* beta, const void* w,
+                    const void* bias, void* t_out, void* y, int M, int C, int N, float eps, void* ws, size_t ws_bytes, void* stream);
+/* bislerp (LD.py:429-518, LatentUpscale.upscale 6639-6654): fp32 NCHW latents [n][c][h][w] -> [n][c][h_new][w_new];
+ * tmp: n*c*h*w_new floats of scratch (the width pass runs first, as in the reference) */
+int ld_op_bislerp(const float* x, float* tmp, float* y, int n, int c, int h, int w, int h_new, int w_new, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,20 +93,154 @@ def detect_clip_config(csd: Dict[str, torch.Tensor], num_heads: int = 12) -> dic
                 max_position_embeddings=int(csd["text_model.embeddings.position_embedding.weight"].shape[0]), hidden_act="quick_gelu")
 
 
-def merge_lora(sd: Dict[str, torch.Tensor], lora: Dict[str, torch.Tensor], strength: float = 1.0, prefix: str = UNET_PREFIX) -> int:
-    """Merge kohya-style LoRA pairs (`lora_unet_<key with _>.lora_up/down.weight`, optional `.alpha`) into the UNet weights
-    in place: W += strength * alpha/rank * up @ down (calculate_weight, LD.py:3407-3424).  Returns the number of merged tensors."""
-    by_flat = {"lora_unet_" + k[len(prefix):-len(".weight")].replace(".", "_"): k for k in sd if k.startswith(prefix) and k.endswith(".weight")}
-    n = 0
-    for name, key in by_flat.items():
-        up, down = lora.get(name + ".lora_up.weight"), lora.get(name + ".lora_down.weight")
-        if up is None or down is None:
+# ------------------------------------------------------------------ LoRA ingestion
+_RES_RENAME = {"in_layers.0": "norm1", "in_layers.2": "conv1", "emb_layers.1": "time_emb_proj", "out_layers.0": "norm2",
+               "out_layers.3": "conv2", "skip_connection": "conv_shortcut"}
+_TOP_RENAME = {"input_blocks.0.0": "conv_in", "out.0": "conv_norm_out", "out.2": "conv_out", "time_embed.0": "time_embedding.linear_1",
+               "time_embed.2": "time_embedding.linear_2"}
+
+
+def _diffusers_module(ldm: str, num_res_blocks) -> Optional[str]:
+    """ldm module path (no .weight/.bias) -> diffusers module path, for the SD1.x UNet layout.  The reference builds the
+    forward table (`unet_to_diffusers`, LD.py:302-394); this is the inverse rule, read off the block numbering: input block
+    1 + sum_{y<x}(R_y + 1) + i is resnet / attention i of down block x, the block after a level's last resnet is its
+    downsampler; output blocks count the same way over the reversed levels, and the last block of a level carries the upsampler."""
+    for k, v in _TOP_RENAME.items():
+        if ldm == k:
+            return v
+    m = re.match(r"^(input_blocks|output_blocks|middle_block)\.(\d+)\.(.*)$", ldm)
+    if not m:
+        return None
+    kind, n, rest = m.group(1), int(m.group(2)), m.group(3)
+
+    def res_or_attn(prefix, i, rest):
+        slot, _, sub = rest.partition(".")
+        if slot == "0":
+            for k, v in _RES_RENAME.items():
+                if sub == k:
+                    return f"{prefix}.resnets.{i}.{v}"
+            return None
+        return f"{prefix}.attentions.{i}.{sub}" if sub and not sub.startswith("conv") else None
+
+    if kind == "middle_block":
+        if n == 1:
+            return f"mid_block.attentions.0.{rest}"
+        for k, v in _RES_RENAME.items():
+            if rest == k:
+                return f"mid_block.resnets.{n // 2}.{v}"
+        return None
+    if kind == "input_blocks":
+        base = 1
+        for x, r in enumerate(num_res_blocks):
+            if n < base + r:
+                return res_or_attn(f"down_blocks.{x}", n - base, rest)
+            if n == base + r:
+                return f"down_blocks.{x}.downsamplers.0.conv" if rest == "0.op" else None
+            base += r + 1
+        return None
+    base = 0
+    for x, r in enumerate(reversed(list(num_res_blocks))):
+        if n < base + r + 1:
+            i = n - base
+            if rest.endswith(".conv") and rest.split(".")[0] in ("1", "2"):
+                return f"up_blocks.{x}.upsamplers.0.conv" if i == r else None
+            return res_or_attn(f"up_blocks.{x}", i, rest)
+        base += r + 1
+    return None
+
+
+def unet_to_diffusers(sd_keys, num_res_blocks, prefix: str = UNET_PREFIX) -> Dict[str, str]:
+    """{diffusers parameter name: ldm parameter name} for every UNet parameter present in `sd_keys` (prefix stripped)."""
+    out = {}
+    for k in sd_keys:
+        if not k.startswith(prefix):
             continue
-        alpha = float(lora[name + ".alpha"]) / down.shape[0] if name + ".alpha" in lora else 1.0
-        delta = torch.mm(up.flatten(start_dim=1).float(), down.flatten(start_dim=1).float()).reshape(sd[key].shape)
-        sd[key] = (sd[key].float() + strength * alpha * delta).to(sd[key].dtype)
-        n += 1
-    return n
+        k = k[len(prefix):]
+        mod, _, leaf = k.rpartition(".")
+        d = _diffusers_module(mod, num_res_blocks)
+        if d is not None:
+            out[f"{d}.{leaf}"] = k
+    return out
+
+
+_CLIP_LORA_LAYERS = ("mlp.fc1", "mlp.fc2", "self_attn.k_proj", "self_attn.q_proj", "self_attn.v_proj", "self_attn.out_proj")
+
+
+def lora_key_map(sd: Dict[str, torch.Tensor], unet_prefix: str = UNET_PREFIX, clip_prefix: str = CLIP_PREFIX) -> Dict[str, str]:
+    """{name a LoRA file may use: checkpoint key it patches} — the naming schemes the reference accepts
+    (model_lora_keys_unet / model_lora_keys_clip, LD.py:577-629): kohya names flattened from the ldm key or from the
+    diffusers key (`lora_unet_...`), diffusers-native attention-processor names (with and without `unet.`), and for the text
+    encoder `lora_te_...`, `lora_te1_...`, `text_encoder....`."""
+    km = {}
+    unet_keys = [k for k in sd if k.startswith(unet_prefix) and k.endswith(".weight")]
+    for k in unet_keys:
+        km["lora_unet_" + k[len(unet_prefix):-len(".weight")].replace(".", "_")] = k
+    nrb = None
+    try:
+        nrb = detect_unet_config(sd, unet_prefix)["num_res_blocks"]
+    except (ValueError, KeyError):
+        pass
+    if nrb is not None:
+        for dk, lk in unet_to_diffusers(unet_keys, nrb, unet_prefix).items():
+            mod = dk[:-len(".weight")]
+            km["lora_unet_" + mod.replace(".", "_")] = unet_prefix + lk
+            native = mod.replace(".to_", ".processor.to_")
+            if native.endswith(".to_out.0"):
+                native = native[:-2]
+            km[native] = km["unet." + native] = unet_prefix + lk
+    rx = re.compile("^" + re.escape(clip_prefix) + r"(?:text_model\.)?encoder\.layers\.(\d+)\.(.+)\.weight$")
+    for k in sd:
+        m = rx.match(k)
+        if m and m.group(2) in _CLIP_LORA_LAYERS:
+            b, c = m.group(1), m.group(2)
+            for fmt in ("lora_te_text_model_encoder_layers_{}_{}", "lora_te1_text_model_encoder_layers_{}_{}"):
+                km[fmt.format(b, c.replace(".", "_"))] = k
+            km[f"text_encoder.text_model.encoder.layers.{b}.{c}"] = k
+    return km
+
+
+class LoraMergeResult(int):
+    """number of merged tensors (an int, as before) with the breakdown attached"""
+    unet = 0
+    clip = 0
+    unmatched: tuple = ()
+
+
+def merge_lora(sd: Dict[str, torch.Tensor], lora: Dict[str, torch.Tensor], strength: float = 1.0, strength_clip: Optional[float] = None,
+               prefix: str = UNET_PREFIX, clip_prefix: str = CLIP_PREFIX) -> LoraMergeResult:
+    """Merge a LoRA file into the checkpoint state dict in place, UNet and text encoder: for every pair the key map resolves,
+    W += strength * (alpha / rank) * up @ down, in fp32, cast back to W's dtype (load_lora LD.py:549-575 + calculate_weight
+    LD.py:3407-3424; the reference patches before sampling, LD.py:3335-3354, so the HIP side only ever sees final weights).
+    `strength_clip` defaults to `strength` (load_lora_for_models takes both, LD.py:6203-6219).  LoRA modules that match
+    nothing are reported (`.unmatched`) and warned about instead of being dropped silently."""
+    import warnings
+    km = lora_key_map(sd, prefix, clip_prefix)
+    sc = strength if strength_clip is None else strength_clip
+    n_unet = n_clip = 0
+    seen = set()
+    modules = sorted({k[:-len(".lora_up.weight")] for k in lora if k.endswith(".lora_up.weight")})
+    for name in modules:
+        up, down = lora[name + ".lora_up.weight"], lora.get(name + ".lora_down.weight")
+        key = km.get(name)
+        if key is None or down is None:
+            continue
+        seen.add(name)
+        is_clip = key.startswith(clip_prefix)
+        scale = sc if is_clip else strength
+        if name + ".alpha" in lora:
+            scale = scale * float(lora[name + ".alpha"]) / down.shape[0]
+        w = sd[key]
+        delta = torch.mm(up.flatten(start_dim=1).float(), down.flatten(start_dim=1).float()).reshape(w.shape)
+        sd[key] = (w.float() + scale * delta).to(w.dtype)
+        n_clip += is_clip
+        n_unet += not is_clip
+    res = LoraMergeResult(n_unet + n_clip)
+    res.unet, res.clip = n_unet, n_clip
+    res.unmatched = tuple(m for m in modules if m not in seen)
+    if res.unmatched:
+        warnings.warn(f"LoRA: {len(res.unmatched)} module(s) match no layer of this checkpoint and were not applied: "
+                      + ", ".join(res.unmatched[:4]) + (" ..." if len(res.unmatched) > 4 else ""))
+    return res
 
 
 def load_state_dict(path: str) -> Dict[str, torch.Tensor]:

@@ -128,4 +128,50 @@ int ld_op_axpby(float* x, float a, const float* y, float b, const float* z, floa
     return axpby_launch(x, a, y, b, z, c, n, (hipStream_t)stream);
 }
 
+int ld_op_linear_ln(const void* x, const void* w_prod, const void* b_prod, const void* gamma, const void* beta, const void* w,
+                    const void* bias, void* t_out, void* y, int M, int C, int N, float eps, void* ws, size_t ws_bytes, void* stream_) {
+    // the UNet's LayerNorm fold (unet.hip, gemm.h) as a stand-alone operator pair, for parity tests:
+    //   t = x · w_prod^T + b_prod         (producer: also emits per-row (sum, sum of squares) partials of the fp16 t)
+    //   y = LayerNorm(t; gamma, beta, eps) · w^T + bias   computed as rstd * (t · W'^T - mu * wsum) + b' on the accumulators
+    if (x == nullptr || w_prod == nullptr || gamma == nullptr || beta == nullptr || w == nullptr || t_out == nullptr || y == nullptr ||
+        ws == nullptr)
+        return LD_ERR_ARG;
+    if (!gemm_ln_fold_available()) return LD_ERR_STATE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t wb = align256((size_t)N * C * sizeof(half_t)), bb = align256((size_t)N * sizeof(half_t)), sb = align256((size_t)N * sizeof(float));
+    const size_t stb = align256((size_t)((C + 63) / 64) * M * 2 * sizeof(float));
+    if (ws_bytes < wb + bb + sb + stb) return LD_ERR_ARG;
+    char* wsp = (char*)ws;
+    half_t* w2 = (half_t*)wsp;
+    half_t* b2 = (half_t*)(wsp + wb);
+    float* wsum = (float*)(wsp + wb + bb);
+    float* stat = (float*)(wsp + wb + bb + sb);
+    int st = ln_fold_launch((const half_t*)w, N, C, (const half_t*)gamma, (const half_t*)beta, (const half_t*)bias, w2, b2, wsum, stream);
+    if (st != LD_OK) return st;
+    int parts = 0;
+    GemmParams a;
+    a.A = (const half_t*)x; a.lda = C;
+    a.W = (const half_t*)w_prod; a.ldw = C;
+    a.M = M; a.N = C; a.K = C;
+    a.bias_n = (const half_t*)b_prod;
+    a.C = (half_t*)t_out; a.ldc = C;
+    a.stat_out = stat; a.stat_parts_out = &parts;
+    st = gemm_launch(a, stream);
+    if (st != LD_OK) return st;
+    GemmParams b;
+    b.A = (const half_t*)t_out; b.lda = C;
+    b.W = w2; b.ldw = C;
+    b.M = M; b.N = N; b.K = C;
+    b.bias_n = b2;
+    b.C = (half_t*)y; b.ldc = N;
+    b.ln_stat = stat; b.ln_parts = parts; b.ln_rows = M;
+    b.ln_inv_c = 1.0f / (float)C; b.ln_eps = eps;
+    b.ln_wsum = wsum;
+    return gemm_launch(b, stream);
+}
+
+int ld_op_bislerp(const float* x, float* tmp, float* y, int n, int c, int h, int w, int h_new, int w_new, void* stream) {
+    return bislerp_launch(x, tmp, y, n, c, h, w, h_new, w_new, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -23,7 +23,8 @@ int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_i
                      const half_t* beta, float eps, int silu, half_t* y, float* partial, hipStream_t stream);
 int layernorm_launch(const half_t* x, const half_t* gamma, const half_t* beta, half_t* y, int rows, int C, float eps,
                      hipStream_t stream);
-int softmax_rows_launch(half_t* s, int rows, int cols, long long ld, hipStream_t stream);
+// in-place row softmax over fp16 scores; cols and ld multiples of 8; valid (0 = cols): columns >= valid are padding (written as 0)
+int softmax_rows_launch(half_t* s, int rows, int cols, long long ld, hipStream_t stream, int valid = 0);
 
 // ---- attention.hip
 struct AttnParams {
@@ -83,3 +84,5 @@ int fill_half_launch(half_t* dst, size_t n, float v, hipStream_t stream);
 // sampler / guidance elementwise (fp32 latents)
 int cfg_combine_launch(const float* den2, float* out, float cfg, size_t n_half, hipStream_t stream);   // out = u + (c-u)*cfg, den2=[u;c]
 int axpby_launch(float* x, float a, const float* y, float b, const float* z, float c, size_t n, hipStream_t stream);  // x = a*x + b*y + c*z
+// bislerp (LD.py:429-518): fp32 NCHW [n][c][h][w] -> [n][c][h_new][w_new]; tmp holds n*c*h*w_new floats (width pass first)
+int bislerp_launch(const float* x, float* tmp, float* y, int n, int c, int h, int w, int h_new, int w_new, hipStream_t stream);

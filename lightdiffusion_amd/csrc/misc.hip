@@ -431,3 +431,60 @@ int ln_fold_launch(const half_t* W, int N, int K, const half_t* gamma, const hal
     hipLaunchKernelGGL(ln_fold_kernel, dim3(N), dim3(256), 0, stream, W, K, gamma, beta, bias, Wout, bout, wsum);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bislerp (LD.py:429-518, the hires-fix latent upscale): a 2-tap resize along ONE axis of an fp32 NCHW tensor whose blend
+// of the two C-vectors slerps their direction and lerps their magnitude.  Called twice (width, then height), like the
+// reference.  HBM-bound and tiny (a [4,4,128,128] latent); one thread per output pixel, channels looped (read twice).
+// Tap positions follow F.interpolate(arange, mode="bilinear", align_corners=False) as generate_bilinear_data builds them.
+namespace {
+__global__ __launch_bounds__(256) void bislerp_axis_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int c, int h,
+                                                           int w, int len_new, int axis_w) {
+    const int ho = axis_w ? h : len_new, wo = axis_w ? len_new : w;
+    const long long total = (long long)n * ho * wo;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int xo = (int)(idx % wo), yo = (int)((idx / wo) % ho), b = (int)(idx / ((long long)wo * ho));
+    const int len_old = axis_w ? w : h, o = axis_w ? xo : yo;
+    float pos = ((float)o + 0.5f) * ((float)len_old / (float)len_new) - 0.5f;
+    pos = fmaxf(pos, 0.f);
+    int lo = (int)floorf(pos);
+    if (lo > len_old - 1) lo = len_old - 1;
+    const int hi = lo + 1 < len_old ? lo + 1 : len_old - 1;
+    const float r = lo >= len_old - 1 ? 0.f : pos - (float)lo;
+    const long long plane = (long long)h * w;
+    const float* pa = x + (long long)b * c * plane + (axis_w ? (long long)yo * w + lo : (long long)lo * w + xo);
+    const float* pb = x + (long long)b * c * plane + (axis_w ? (long long)yo * w + hi : (long long)hi * w + xo);
+    float na = 0.f, nb = 0.f, dot = 0.f;
+    for (int ch = 0; ch < c; ++ch) {
+        const float a = pa[ch * plane], bb = pb[ch * plane];
+        na += a * a;
+        nb += bb * bb;
+        dot += a * bb;
+    }
+    na = sqrtf(na);
+    nb = sqrtf(nb);
+    const float ia = na > 0.f ? 1.f / na : 0.f, ib = nb > 0.f ? 1.f / nb : 0.f;
+    dot *= ia * ib;                                        // cosine of the angle between the two normalised vectors
+    const float om = acosf(dot), so = sinf(om);
+    const float wa = sinf((1.f - r) * om) / so * ia, wb = sinf(r * om) / so * ib;
+    const float mag = na * (1.f - r) + nb * r;
+    const long long oplane = (long long)ho * wo;
+    float* py = y + (long long)b * c * oplane + (long long)yo * wo + xo;
+    for (int ch = 0; ch < c; ++ch) {
+        const float a = pa[ch * plane], bb = pb[ch * plane];
+        float v = (wa * a + wb * bb) * mag;
+        if (dot > 1.f - 1e-5f) v = a;                      // same direction
+        if (dot < 1e-5f - 1.f) v = a * (1.f - r) + bb * r; // polar opposites
+        py[ch * oplane] = v;
+    }
+    }
+}
+}  // namespace
+
+int bislerp_launch(const float* x, float* tmp, float* y, int n, int c, int h, int w, int h_new, int w_new, hipStream_t stream) {
+    if (x == nullptr || tmp == nullptr || y == nullptr || n <= 0 || c <= 0 || h <= 0 || w <= 0 || h_new <= 0 || w_new <= 0) return LD_ERR_ARG;
+    hipLaunchKernelGGL(bislerp_axis_kernel, dim3(grid_for((long long)n * h * w_new, 256)), dim3(256), 0, stream, x, tmp, n, c, h, w, w_new, 1);
+    hipLaunchKernelGGL(bislerp_axis_kernel, dim3(grid_for((long long)n * h_new * w_new, 256)), dim3(256), 0, stream, tmp, y, n, c, h, w_new,
+                       h_new, 0);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}

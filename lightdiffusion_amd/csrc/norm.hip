@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
 }
 
 // row softmax in place over fp16 scores (VAE mid-block attention: one head, L = H*W keys)
-__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ s, int cols, long long ld) {
+// `valid` <= cols: columns valid..cols-1 are padding (scores ignored, probabilities written as zeros).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ s, int cols, int valid, long long ld) {
     __shared__ float red[4];
     half_t* row = s + (long long)blockIdx.x * ld;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ 
         float v[8];
         unpack8(ld16(row + c * 8), v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, v[j]);
+        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, c * 8 + j < valid ? v[j] : -INFINITY);
     }
     mx = wave_max(mx);
     if (lane == 0) red[wid] = mx;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ 
         float v[8];
         unpack8(ld16(row + c * 8), v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += __expf(v[j] - mx);
+        for (int j = 0; j < 8; ++j) sum += c * 8 + j < valid ? __expf(v[j] - mx) : 0.f;
     }
     sum = wave_sum(sum);
     if (lane == 0) red[wid] = sum;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ 
         float v[8];
         unpack8(ld16(row + c * 8), v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = __expf(v[j] - mx) * inv;
+        for (int j = 0; j < 8; ++j) v[j] = c * 8 + j < valid ? __expf(v[j] - mx) * inv : 0.f;
         st16(row + c * 8, pack8(v));
     }
 }
@@ -252,8 +253,8 @@ int layernorm_launch(const half_t* x, const half_t* gamma, const half_t* beta, h
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
 
-int softmax_rows_launch(half_t* s, int rows, int cols, long long ld, hipStream_t stream) {
-    if (s == nullptr || rows <= 0 || cols % 8 || ld % 8) return LD_ERR_SHAPE;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, s, cols, ld);
+int softmax_rows_launch(half_t* s, int rows, int cols, long long ld, hipStream_t stream, int valid) {
+    if (s == nullptr || rows <= 0 || cols % 8 || ld % 8 || valid > cols) return LD_ERR_SHAPE;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, s, cols, valid > 0 ? valid : cols, ld);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }

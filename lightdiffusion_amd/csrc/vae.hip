@@ -217,34 +217,37 @@ struct VRun {
             p.C = qk; p.ldc = 2 * C;
             ex.gemm(p);
         }
-        half_t* vt = ar.halfs(M * C);
+        // key axis padded to a multiple of 8 (16-byte rows): pad keys get zero scores, zero probabilities and a finite V^T
+        // column (bias only), so any latent size works (63x63, 65x65 ...), as in the reference
+        const int Lp = (L + 7) & ~7;
+        half_t* vt = ar.halfs((size_t)n * C * Lp);
         {   // V^T[b] = Wv · g_b^T + bv (bias along rows)
             GemmParams p;
             p.A = P(aw.v_w); p.lda = C; p.sA = 0;
             p.W = g; p.ldw = C; p.sW = (long long)L * C;
-            p.M = C; p.N = L; p.K = C; p.batch = n;
+            p.M = C; p.N = Lp; p.n_valid = L; p.K = C; p.batch = n;
             p.bias_m = P(aw.v_b);
-            p.C = vt; p.ldc = L; p.sC = (long long)C * L;
+            p.C = vt; p.ldc = Lp; p.sC = (long long)C * Lp;
             ex.gemm(p);
         }
-        half_t* s = ar.halfs((size_t)n * L * L);
+        half_t* s = ar.halfs((size_t)n * L * Lp);
         {   // S_b = Q_b K_b^T / sqrt(C)
             GemmParams p;
             p.A = qk; p.lda = 2 * C; p.sA = (long long)L * 2 * C;
             p.W = qk + C; p.ldw = 2 * C; p.sW = (long long)L * 2 * C;
-            p.M = L; p.N = L; p.K = C; p.batch = n;
+            p.M = L; p.N = Lp; p.n_valid = L; p.K = C; p.batch = n;
             p.alpha = 1.0f / sqrtf((float)C);
-            p.C = s; p.ldc = L; p.sC = (long long)L * L;
+            p.C = s; p.ldc = Lp; p.sC = (long long)L * Lp;
             ex.gemm(p);
         }
         ex.launches += 1;
-        if (!ex.dry && ex.status == LD_OK) ex.note(softmax_rows_launch(s, n * L, L, L, ex.stream));
+        if (!ex.dry && ex.status == LD_OK) ex.note(softmax_rows_launch(s, n * L, Lp, Lp, ex.stream, L));
         half_t* o = g;   // reuse
-        {   // O_b = P_b V_b  (W operand = V^T [C][L])
+        {   // O_b = P_b V_b  (W operand = V^T [C][Lp]; the pad keys carry zero probability)
             GemmParams p;
-            p.A = s; p.lda = L; p.sA = (long long)L * L;
-            p.W = vt; p.ldw = L; p.sW = (long long)C * L;
-            p.M = L; p.N = C; p.K = L; p.batch = n;
+            p.A = s; p.lda = Lp; p.sA = (long long)L * Lp;
+            p.W = vt; p.ldw = Lp; p.sW = (long long)C * Lp;
+            p.M = L; p.N = C; p.K = Lp; p.batch = n;
             p.C = o; p.ldc = C; p.sC = (long long)L * C;
             ex.gemm(p);
         }
@@ -462,7 +465,7 @@ int ld_vae_reserve(ld_vae* v, int max_b, int max_h, int max_w) {
 int ld_vae_decode(ld_vae* v, const float* z, float* out, int b, int h, int w, void* stream) {
     if (v == nullptr || z == nullptr || out == nullptr) return LD_ERR_ARG;
     if (v->ws_base == nullptr || !v->pt.all_loaded()) return LD_ERR_STATE;
-    if (b < 1 || h < 1 || w < 1 || ((h * w) & 7)) return LD_ERR_SHAPE;
+    if (b < 1 || h < 1 || w < 1) return LD_ERR_SHAPE;
     if (b != v->plan_b || h != v->plan_h || w != v->plan_w) {
         size_t peak = 0;
         const int st = run_decode(v, true, nullptr, nullptr, b, h, w, nullptr, &peak);
@@ -479,7 +482,7 @@ int ld_vae_encode(ld_vae* v, const float* pixels_nchw, float* moments, int b, in
     if (v == nullptr || pixels_nchw == nullptr || moments == nullptr) return LD_ERR_ARG;
     if (!v->cfg.with_encoder) return LD_ERR_STATE;
     if (v->ws_base == nullptr || !v->pt.all_loaded()) return LD_ERR_STATE;
-    if (b < 1 || h < 1 || w < 1 || ((h * w) & 7)) return LD_ERR_SHAPE;
+    if (b < 1 || h < 1 || w < 1) return LD_ERR_SHAPE;
     size_t peak = 0;
     int st = run_encode(v, true, nullptr, nullptr, b, h, w, nullptr, &peak);
     if (st != LD_OK) return st;

@@ -114,34 +114,15 @@ class VAEEncode:
         return ({"samples": vae.encode(pixels[:, :, :, :3])},)
 
 
-def bislerp(samples: torch.Tensor, width: int, height: int) -> torch.Tensor:
-    """Latent upscale of the hires-fix path (bislerp, LD.py:429-518): 2-tap separable resize along W then H whose blend of
-    the two C-vectors slerps the direction and lerps the magnitude.  Runs once per image (torch ops on `samples.device`)."""
-    def taps(n_src, n_dst, dev):
-        pos = ((torch.arange(n_dst, dtype=torch.float32, device=dev) + 0.5) * (n_src / n_dst) - 0.5).clamp_(min=0.0)
-        lo = pos.floor().clamp_(max=n_src - 1)
-        fr = torch.where(lo >= n_src - 1, torch.zeros_like(pos), pos - lo)
-        lo = lo.long()
-        return lo, (lo + 1).clamp_(max=n_src - 1), fr
-
-    def blend(a, b, r):
-        na, nb = a.norm(dim=-1, keepdim=True), b.norm(dim=-1, keepdim=True)
-        ua = torch.where(na > 0, a / na, torch.zeros_like(a))
-        ub = torch.where(nb > 0, b / nb, torch.zeros_like(b))
-        cw = (ua * ub).sum(dim=-1, keepdim=True)
-        om = torch.acos(cw)
-        so = torch.sin(om)
-        res = (torch.sin((1.0 - r) * om) / so) * ua + (torch.sin(r * om) / so) * ub
-        res = res * (na * (1.0 - r) + nb * r)
-        res = torch.where(cw > 1 - 1e-5, a, res)
-        return torch.where(cw < 1e-5 - 1, a * (1.0 - r) + b * r, res)
-
-    x = samples.float().permute(0, 2, 3, 1)
-    lo, hi, fr = taps(x.shape[2], width, x.device)
-    x = blend(x[:, :, lo], x[:, :, hi], fr.view(1, 1, -1, 1))
-    lo, hi, fr = taps(x.shape[1], height, x.device)
-    x = blend(x[:, lo], x[:, hi], fr.view(1, -1, 1, 1))
-    return x.permute(0, 3, 1, 2).to(samples.dtype)
+def bislerp(samples: torch.Tensor, width: int, height: int, device=None) -> torch.Tensor:
+    """Latent upscale of the hires-fix path (bislerp, LD.py:429-518) on the HIP kernel `ld_op_bislerp`: a 2-tap separable
+    resize along W then H whose blend of the two C-vectors slerps the direction and lerps the magnitude.  A host tensor
+    (what KSampler2 returns, LD.py:3156-3203) is uploaded, resized on the device and returned to the host."""
+    from . import ops
+    if samples.is_cuda:
+        return ops.bislerp(samples, width, height)
+    dev = torch.device(device if device is not None else "cuda:0")
+    return ops.bislerp(samples.to(dev), width, height).to(samples.device)
 
 
 class LatentUpscale:
@@ -162,14 +143,17 @@ def _attach(unet: MI355XUNet, device) -> ModelPatcher:
     return patcher
 
 
-def load_synthetic(device="cuda:0", max_batch: int = 1, max_hw=(64, 64), tiny: bool = False, seed: int = 0, tokenizer_dir: Optional[str] = None):
-    """(model, clip, vae) with deterministic random-init weights — the offline stand-in for a downloaded checkpoint."""
+def load_synthetic(device="cuda:0", max_batch: int = 1, max_hw=(64, 64), tiny: bool = False, seed: int = 0, tokenizer_dir: Optional[str] = None,
+                   max_tokens: int = 77):
+    """(model, clip, vae) with deterministic random-init weights — the offline stand-in for a downloaded checkpoint.
+    `max_batch` / `max_hw` / `max_tokens` only pre-size the workspaces: larger batches, latents (hires pass) or prompts
+    (more 77-token chunks) grow them on first use (MI355XUNet._ensure, MI355XVAE._ensure)."""
     ucfg, vcfg, ccfg = (W.tiny_unet_config(), W.tiny_vae_config(), W.tiny_clip_config()) if tiny else \
         (W.sd15_unet_config(), W.sd15_vae_config(), W.sd15_clip_config())
     if tiny:
         ccfg = dict(ccfg, hidden_size=ucfg["context_dim"])
     gen = lambda name, shape: W.synth_tensor(name, shape, seed)
-    unet = MI355XUNet(ucfg, gen, device=device, max_batch=2 * max_batch, max_hw=max_hw)
+    unet = MI355XUNet(ucfg, gen, device=device, max_batch=2 * max_batch, max_hw=max_hw, max_tokens=max_tokens)
     vae = MI355XVAE(vcfg, gen, device=device, max_batch=max_batch, max_hw=max_hw, with_encoder=True)
     tok = PromptTokenizer.from_pretrained(tokenizer_dir) if tokenizer_dir else None
     clip = CLIP(CLIPTextModelHIP(ccfg, W.synth_state_dict(W.clip_param_shapes(ccfg), seed), device=device), tok)
@@ -181,17 +165,20 @@ class CheckpointLoaderSimple:
     architecture is detected from the keys (checkpoint.detect_*), weights are repacked on the device by the C library."""
 
     def __init__(self, device="cuda:0", max_batch: int = 1, max_hw=(64, 64), tokenizer_dir: Optional[str] = None,
-                 clip_heads: int = 12, unet_heads: int = 8):
+                 clip_heads: int = 12, unet_heads: int = 8, max_tokens: int = 77):
         self.device, self.max_batch, self.max_hw, self.tokenizer_dir = device, max_batch, max_hw, tokenizer_dir
-        self.clip_heads, self.unet_heads = clip_heads, unet_heads
+        self.clip_heads, self.unet_heads, self.max_tokens = clip_heads, unet_heads, max_tokens
 
-    def load_checkpoint(self, ckpt_name, output_vae=True, output_clip=True, lora: Optional[dict] = None, lora_strength: float = 1.0):
+    def load_checkpoint(self, ckpt_name, output_vae=True, output_clip=True, lora=None, lora_strength: float = 1.0,
+                        lora_strength_clip: Optional[float] = None):
+        """`lora`: a LoRA state dict or a path to one; merged into UNet AND text-encoder weights before they are uploaded
+        (load_lora_for_models, LD.py:6203-6219: strength_model / strength_clip)."""
         from . import checkpoint as CK
         sd = CK.load_state_dict(ckpt_name) if isinstance(ckpt_name, str) else dict(ckpt_name)
-        if lora:
-            CK.merge_lora(sd, lora, lora_strength)
+        if lora is not None:
+            CK.merge_lora(sd, CK.load_state_dict(lora) if isinstance(lora, str) else lora, lora_strength, lora_strength_clip)
         unet = MI355XUNet(CK.detect_unet_config(sd, num_heads=self.unet_heads), sd, device=self.device, max_batch=2 * self.max_batch,
-                          max_hw=self.max_hw)
+                          max_hw=self.max_hw, max_tokens=self.max_tokens)
         vcfg, has_enc = CK.detect_vae_config(sd)
         vae = MI355XVAE(vcfg, sd, device=self.device, max_batch=self.max_batch, max_hw=self.max_hw, with_encoder=has_enc)
         csd = CK.clip_state_dict(sd)
@@ -213,3 +200,56 @@ def txt2img(model, clip, vae, prompt_tokens, negative_tokens, width=512, height=
         lat = LatentUpscale().upscale(lat, "bislerp", width * 2, height * 2)[0]
         lat = KSampler2().sample(model, seed, 10, 8, "euler_ancestral", "normal", pos, neg, lat, denoise=0.45)[0]
     return VAEDecode().decode(vae, lat)[0]
+
+
+def txt2img_sharded(model, clip, vae, prompt_tokens, negative_tokens, width=512, height=512, global_batch=8, seed=0, steps=20, cfg=7.0,
+                    sampler_name="euler_ancestral", scheduler="normal", gather: bool = True, run_sampler=None):
+    """Batched generation sharded over the ranks of one node (BASELINE config #4), in the call order of the
+    reference's `pipeline()` (LD.py:10001-10086): rank 0 runs CLIP and broadcasts [cond, uncond] once (RCCL over xGMI;
+    the only data-path collective), every rank takes a contiguous block of the global batch, draws the FULL-batch noise
+    from the single seed on its host generator and keeps its rows (initial noise and every ancestral step), runs its own
+    sampler loop on its own UNet replica and decodes its images; the images are gathered on rank 0 (None elsewhere).
+    Row for row the result equals the single-process run of the same global batch.
+    `run_sampler(noise, latent, pos, neg, sigmas, extra_options) -> latents` replaces the device sampler loop in the
+    CPU (gloo) test of this host logic; the product path never passes it."""
+    import torch.distributed as tdist
+    from . import dist as D
+    world = D.world_size()
+    rank = tdist.get_rank() if world > 1 else 0
+    enc = lambda t: clip.encode_from_tokens(clip.tokenize(t) if isinstance(t, str) else t, return_pooled=False)
+    pc = nc = shapes = None
+    if rank == 0:
+        pc, nc = enc(prompt_tokens), enc(negative_tokens)
+        shapes = [tuple(pc.shape), tuple(nc.shape)]
+    if world > 1:
+        box = [shapes]
+        tdist.broadcast_object_list(box, src=0)                 # token counts (77 x chunks): a few bytes of metadata
+        on_gpu = tdist.get_backend() == "nccl"
+        pc, nc = D.broadcast_conditioning([pc, nc], box[0], src=0, device=None if on_gpu else torch.device("cpu"))
+        pc, nc = pc.cpu(), nc.cpu()
+    rows = D.shard_rows(global_batch, rank, world)
+    b = rows.stop - rows.start
+    lat_shape = (global_batch, 4, height // 8, width // 8)
+    if b > 0:
+        noise = D.full_batch_noise(lat_shape, seed, rows)
+        latent = torch.zeros((b,) + lat_shape[1:])
+        sigmas = sampling.calculate_sigmas(model.get_model_object("model_sampling"), scheduler, steps)
+        dev = model.load_device
+        extra = {}
+        if sampler_name == "euler_ancestral":     # per-step noise: full-batch draw on the host generator, this rank's rows
+            extra["noise_sampler"] = sampling.host_noise_sampler(torch.empty((b,) + lat_shape[1:], device=dev), rows, global_batch)
+        pos, neg = [[pc, {"pooled_output": None}]], [[nc, {"pooled_output": None}]]
+        if run_sampler is not None:
+            samples = run_sampler(noise, latent, pos, neg, sigmas, extra)
+        else:
+            samples = sampling.sample(model, noise, pos, neg, cfg, dev, sampling.ksampler(sampler_name, extra), sigmas,
+                                      model.model_options, latent_image=latent, seed=seed).cpu()
+        images = vae.decode(samples)
+    else:
+        images = torch.zeros((0, height, width, 3))
+    if not gather or world == 1:
+        return images
+    if tdist.get_backend() == "nccl":                          # 6.3 MB per rank as uint8 (SURVEY §8e)
+        g = D.gather_images((images * 255.0).round().to(torch.uint8).to(model.load_device), dst=0)
+        return None if g is None else g.cpu().float() / 255.0
+    return D.gather_images(images, dst=0)

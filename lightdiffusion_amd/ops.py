@@ -26,8 +26,19 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+_WS = {}
+
+
 def _ws(nbytes: int, device) -> torch.Tensor:
-    return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+    """Per-device scratch for split-K partials / GEGLU repack, grown on demand and reused: the operator seam is also the CLIP
+    path (60+ calls per prompt), so no per-call allocation.  Stream-ordered reuse is safe: every op that takes it runs on
+    the current stream and is done with it when the next one starts."""
+    key = (torch.device(device).type, torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
@@ -43,6 +54,20 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     check(lib().ld_op_linear(_p(x), _p(weight), _p(bias), _p(residual), _p(y), M, N, K, alpha, code, _p(ws), ws.numel(), _stream()),
           "ld_op_linear")
     return y
+
+
+def linear_ln(x: torch.Tensor, w_prod: torch.Tensor, b_prod: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+              weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float = 1e-5):
+    """The UNet's LayerNorm fold as an operator pair: t = x @ w_prod.T + b_prod;  y = LayerNorm(t) @ weight.T + bias with the
+    normalisation finished on the GEMM accumulators (no LayerNorm launch, no normalised tensor).  Returns (t, y)."""
+    M, C = x.shape
+    N = weight.shape[0]
+    t = torch.empty(M, C, dtype=torch.float16, device=x.device)
+    y = torch.empty(M, N, dtype=torch.float16, device=x.device)
+    ws = _ws(2 * N * C + 8 * N + 8 * ((C + 63) // 64) * M + 4096, x.device)
+    check(lib().ld_op_linear_ln(_p(x), _p(w_prod), _p(b_prod), _p(gamma), _p(beta), _p(weight), _p(bias), _p(t), _p(y), M, C, N, eps,
+                                _p(ws), ws.numel(), _stream()), "ld_op_linear_ln")
+    return t, y
 
 
 def repack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
@@ -139,3 +164,125 @@ def axpby_(x: torch.Tensor, a: float, y: Optional[torch.Tensor] = None, b: float
     """x <- a*x + b*y + c*z in place on fp32 latents (the samplers' update arithmetic)."""
     check(lib().ld_op_axpby(_p(x), float(a), _p(y), float(b), _p(z), float(c), x.numel(), _stream()), "ld_op_axpby")
     return x
+
+
+def bislerp(samples: torch.Tensor, width: int, height: int) -> torch.Tensor:
+    """bislerp(samples, width, height) of LD.py:429-518 on the device: [n,c,h,w] -> [n,c,height,width] (fp32 math)."""
+    x = samples.float().contiguous()
+    n, c, h, w = x.shape
+    tmp = torch.empty(n, c, h, width, dtype=torch.float32, device=x.device)
+    y = torch.empty(n, c, height, width, dtype=torch.float32, device=x.device)
+    check(lib().ld_op_bislerp(_p(x), _p(tmp), _p(y), n, c, h, w, height, width, _stream()), "ld_op_bislerp")
+    return y.to(samples.dtype)
+
+
+# ------------------------------------------------------------------ the `operations=` namespace (secondary seam)
+# The reference builds every network from an injectable namespace (`operations=ops`: UNetModel1 LD.py:5338, ResBlock1
+# 5207, SpatialTransformer 4179, CrossAttention 4005, FeedForward 3908; BaseModel picks `manual_cast` or
+# `disable_weight_init`, LD.py:5809-5816).  The classes below have the torch constructor signatures and state-dict names
+# (`weight`, `bias`) of LD.py:2342-2429 and run their forward on the HIP kernels.  Like `disable_weight_init` they do not
+# initialise parameters (reset_parameters is a no-op, LD.py:2363); like `manual_cast` they accept any float input dtype
+# and return it.  Feature maps keep torch's logical NCHW shape in channels_last memory, which *is* the kernels' NHWC
+# layout, so a chain of these modules moves no data between ops.
+import torch.nn as nn  # noqa: E402
+
+
+def _to_f16_cl(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.float16).contiguous(memory_format=torch.channels_last)
+
+
+class _NoInit:
+    def reset_parameters(self):
+        return None
+
+
+class Linear(_NoInit, nn.Module):
+    def __init__(self, in_features, out_features, bias=True, device=None, dtype=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features, device=device, dtype=dtype), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_features, device=device, dtype=dtype), requires_grad=False) if bias else None
+
+    def forward(self, x):
+        w = self.weight.to(x.device, torch.float16)
+        b = None if self.bias is None else self.bias.to(x.device, torch.float16)
+        return linear(x.to(torch.float16).contiguous(), w.contiguous(), b).to(x.dtype)
+
+
+class Conv2d(_NoInit, nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 padding_mode="zeros", device=None, dtype=None):
+        super().__init__()
+        k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        st = stride if isinstance(stride, int) else stride[0]
+        pd = padding if isinstance(padding, int) else padding[0]
+        if k not in (1, 3) or pd != k // 2 or dilation not in (1, (1, 1)) or groups != 1 or padding_mode != "zeros":
+            raise NotImplementedError("MI355X Conv2d: kernel 1 or 3 with padding k//2, no dilation / groups (all the SD1.x UNet and VAE use)")
+        self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding = in_channels, out_channels, (k, k), (st, st), (pd, pd)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, k, k, device=device, dtype=dtype), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(out_channels, device=device, dtype=dtype), requires_grad=False) if bias else None
+        self._packed = None
+
+    def _weights(self, device):
+        key = (self.weight.data_ptr(), self.weight._version, str(device))
+        if self._packed is None or self._packed[0] != key:
+            wp = repack_conv_weight(self.weight.detach().to(device))
+            b = torch.zeros(self.out_channels, dtype=torch.float16, device=device) if self.bias is None else self.bias.detach().to(device, torch.float16)
+            self._packed = (key, wp, b.contiguous())
+        return self._packed[1], self._packed[2]
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        xc = _to_f16_cl(x)
+        wp, b = self._weights(x.device)
+        y = conv2d(xc.permute(0, 2, 3, 1), wp, b, self.kernel_size[0], self.stride[0])          # a view: channels_last memory is NHWC
+        return y.permute(0, 3, 1, 2).to(x.dtype)
+
+
+class GroupNorm(_NoInit, nn.Module):
+    def __init__(self, num_groups, num_channels, eps=1e-5, affine=True, device=None, dtype=None):
+        super().__init__()
+        if num_groups != 32 or not affine:
+            raise NotImplementedError("MI355X GroupNorm: 32 groups, affine (Normalize, LD.py:3931-3939)")
+        self.num_groups, self.num_channels, self.eps = num_groups, num_channels, eps
+        self.weight = nn.Parameter(torch.empty(num_channels, device=device, dtype=dtype), requires_grad=False)
+        self.bias = nn.Parameter(torch.empty(num_channels, device=device, dtype=dtype), requires_grad=False)
+
+    def forward(self, x):
+        xc = _to_f16_cl(x) if x.dim() == 4 else x.to(torch.float16).transpose(1, -1).contiguous()
+        nhwc = xc.permute(0, 2, 3, 1) if x.dim() == 4 else xc
+        y = group_norm(nhwc, self.weight.to(x.device, torch.float16), self.bias.to(x.device, torch.float16), self.eps)
+        y = y.permute(0, 3, 1, 2) if x.dim() == 4 else y.transpose(1, -1)
+        return y.to(x.dtype)
+
+
+class LayerNorm(_NoInit, nn.Module):
+    def __init__(self, normalized_shape, eps=1e-5, elementwise_affine=True, bias=True, device=None, dtype=None):
+        super().__init__()
+        c = normalized_shape if isinstance(normalized_shape, int) else normalized_shape[-1]
+        if not isinstance(normalized_shape, int) and len(normalized_shape) != 1:
+            raise NotImplementedError("MI355X LayerNorm: last-dimension normalisation")
+        self.normalized_shape, self.eps = (c,), eps
+        self.weight = nn.Parameter(torch.empty(c, device=device, dtype=dtype), requires_grad=False) if elementwise_affine else None
+        self.bias = nn.Parameter(torch.empty(c, device=device, dtype=dtype), requires_grad=False) if elementwise_affine and bias else None
+
+    def forward(self, x):
+        c = self.normalized_shape[0]
+        g = torch.ones(c, dtype=torch.float16, device=x.device) if self.weight is None else self.weight.to(x.device, torch.float16)
+        b = torch.zeros(c, dtype=torch.float16, device=x.device) if self.bias is None else self.bias.to(x.device, torch.float16)
+        return layer_norm(x.to(torch.float16).contiguous(), g, b, self.eps).to(x.dtype)
+
+
+def conv_nd(dims, *args, **kwargs):
+    """disable_weight_init.conv_nd (LD.py:2407-2412): only dims == 2 exists in the SD1.x networks."""
+    if dims == 2:
+        return Conv2d(*args, **kwargs)
+    raise ValueError(f"unsupported dimensions: {dims}")
+
+
+def optimized_attention(q, k, v, heads, mask=None):
+    """The module-global attention function of LD.py:3966-3988: q [b,Lq,heads*d], k / v [b,Lk,heads*d] -> [b,Lq,heads*d]."""
+    if mask is not None:
+        raise NotImplementedError("MI355X optimized_attention: the SD1.x UNet passes no mask (LD.py:4028-4036)")
+    f16 = lambda t: t.to(torch.float16).contiguous()
+    return attention(f16(q), f16(k), f16(v), heads).to(q.dtype)

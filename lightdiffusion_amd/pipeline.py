@@ -26,12 +26,12 @@ class CFGDenoiser:
         self.den = torch.zeros(batch, c, h, w, dtype=torch.float32, device=dev)
         self.use_graph = use_graph
         self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._graph_key = None
 
     def set_context(self, uncond: torch.Tensor, cond: torch.Tensor) -> None:
         """uncond / cond: [1 or B, T, D].  Batched as the reference batches them: [uncond x B ; cond x B] (LD.py:2515-2547)."""
         rep = lambda t: t if t.shape[0] == self.batch else t.expand(self.batch, -1, -1)
         self.unet.set_context(torch.cat([rep(uncond), rep(cond)]).contiguous())
-        self._graph = None
 
     def _body(self) -> None:
         self.unet.forward(self.x2, self.sigma2, out=self.den2)
@@ -50,6 +50,31 @@ class CFGDenoiser:
         with torch.cuda.graph(g):
             self._body()
         self._graph = g
+        self._graph_key = self._state_key()
+
+    def _state_key(self):
+        # what the captured launches bake in besides the static buffers: the workspace addresses (reserve epoch) and the
+        # number of context tokens (a kernel argument).  The context VALUES live at fixed addresses and may change freely.
+        return (self.unet.reserve_epoch, self.unet.ctx_shape)
+
+    def _launch(self) -> torch.Tensor:
+        if not self.use_graph:
+            self._body()
+        else:
+            if self._graph is None or self._graph_key != self._state_key():
+                self._capture()
+            self._graph.replay()
+        return self.den
+
+    def run(self, x: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
+        """x [B,C,h,w] fp32, timestep [B] fp32 (sigma per sample), both on the device: no host read, so the host runs ahead
+        of the GPU across steps.  Returns the static output buffer (valid until the next call)."""
+        b = self.batch
+        self.x2[:b].copy_(x)
+        self.x2[b:].copy_(x)
+        self.sigma2[:b].copy_(timestep)
+        self.sigma2[b:].copy_(timestep)
+        return self._launch()
 
     def __call__(self, x: torch.Tensor, sigma: float) -> torch.Tensor:
         """x [B,C,h,w] fp32 on the device, sigma a host scalar -> guided denoised x0 [B,C,h,w] (static buffer)."""
@@ -57,10 +82,4 @@ class CFGDenoiser:
         self.x2[:b].copy_(x)
         self.x2[b:].copy_(x)
         self.sigma2.fill_(float(sigma))
-        if not self.use_graph:
-            self._body()
-        else:
-            if self._graph is None:
-                self._capture()
-            self._graph.replay()
-        return self.den
+        return self._launch()

@@ -16,7 +16,7 @@ from typing import Callable, Dict, Optional, Union
 import torch
 
 from . import weights as W
-from ._lib import F16, F32, UNetConfig, VAEConfig, check, lib
+from ._lib import ERR_SHAPE, F16, F32, LDError, UNetConfig, VAEConfig, check, lib
 
 WeightSource = Union[Dict[str, torch.Tensor], Callable[[str, tuple], torch.Tensor]]
 
@@ -74,8 +74,30 @@ class MI355XUNet:
             check(lib().ld_unet_create(C.byref(c), C.byref(self._h)), "ld_unet_create")
             _load_params(self._h, lib().ld_unet_param_count, lib().ld_unet_param_info, lib().ld_unet_load_param, weights,
                          self.device, ("", "model.diffusion_model."))
+        self._reserved = (0, 0, 0, 0)
+        self.reserve_epoch = 0           # bumped whenever the workspace moves: captured hipGraphs of older epochs are stale
+        self.reserve(max_batch, max_hw, max_tokens)
+        self._ctx_ref = None             # device copy of the context the resident K / V^T were projected from
+        self._ctx_token = None           # per-run token of our own sampling stack (sampling.sampling_function)
+        self.ctx_shape = None            # (n, tokens) of the resident context
+        self._denoisers = {}
+
+    def reserve(self, max_batch: int, max_hw=(64, 64), max_tokens: int = 77) -> None:
+        """(Re)size the activation workspace.  Growing it frees and reallocates: the context must be set again and every
+        captured graph is stale (`reserve_epoch`)."""
+        with torch.cuda.device(self.device):
             check(lib().ld_unet_reserve(self._h, max_batch, max_hw[0], max_hw[1], max_tokens), "ld_unet_reserve")
-        self._ctx_key = None
+        self._reserved = (max_batch, max_hw[0], max_hw[1], max_tokens)
+        self.reserve_epoch += 1
+        self._ctx_ref = self._ctx_token = self.ctx_shape = None
+        self._denoisers = {}
+
+    def _ensure(self, n: int, h: int, w: int, tokens: int) -> None:
+        """Lazy re-reserve (the reference accepts any batch, latent size and number of 77-token chunks): grow the plan when a
+        call exceeds it instead of failing with ERR_SHAPE."""
+        mn, mh, mw, mt = self._reserved
+        if n > mn or h > mh or w > mw or tokens > mt:
+            self.reserve(max(n, mn), (max(h, mh), max(w, mw)), max(tokens, mt))
 
     def __del__(self):
         try:
@@ -109,10 +131,13 @@ class MI355XUNet:
         if ctx.dtype not in (torch.float16, torch.float32):
             ctx = ctx.float()
         ctx = ctx.contiguous()
+        mn, mh, mw, _ = self._reserved
+        self._ensure(ctx.shape[0], mh, mw, ctx.shape[1])
         with torch.cuda.device(self.device):
             check(lib().ld_unet_set_context(self._h, ctx.data_ptr(), F32 if ctx.dtype == torch.float32 else F16, ctx.shape[0],
                                             ctx.shape[1], _stream()), "ld_unet_set_context")
-        self._ctx_key = None
+        self._ctx_ref = self._ctx_token = None
+        self.ctx_shape = (ctx.shape[0], ctx.shape[1])
 
     def forward(self, x: torch.Tensor, sigma: torch.Tensor, out: Optional[torch.Tensor] = None, eps_only: bool = False) -> torch.Tensor:
         """x [N,4,h,w] fp32 (device), sigma [N] fp32 (device) -> denoised [N,4,h,w] fp32 = x - eps*sigma."""
@@ -121,6 +146,9 @@ class MI355XUNet:
         if out is None:
             out = torch.empty_like(x)
         n, _, h, w = x.shape
+        mn, mh, mw, _ = self._reserved
+        if n > mn or h > mh or w > mw:
+            raise LDError(ERR_SHAPE, f"ld_unet_forward: input {n}x{h}x{w} exceeds the reserved plan {mn}x{mh}x{mw} (reserve(), then set_context)")
         with torch.cuda.device(self.device):
             check(lib().ld_unet_forward(self._h, x.data_ptr(), sigma.data_ptr(), out.data_ptr(), n, h, w, int(eps_only), _stream()),
                   "ld_unet_forward")
@@ -139,18 +167,48 @@ class MI355XUNet:
         return {k: (ms[i], fl[i], nl[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
 
     # -- the reference's plugin seam
+    def _sync_context(self, ctx: torch.Tensor, n: int, h: int, w: int, token=None) -> None:
+        """Make the resident cross-attention K / V^T those of `ctx`.  The reference re-concatenates the context every step
+        (cond_cat, LD.py:2471-2489) into a fresh tensor whose address the caching allocator recycles, so identity proves
+        nothing: the CONTENT is compared with the device copy of what was projected (one small elementwise kernel + a host
+        read per call).  Our own sampling stack passes a never-reused per-run `token` instead and skips the comparison."""
+        self._ensure(n, h, w, ctx.shape[1])
+        if token is not None and token == self._ctx_token and self.ctx_shape == (ctx.shape[0], ctx.shape[1]):
+            return
+        c = ctx.to(self.device)
+        same = self._ctx_ref is not None and self._ctx_ref.shape == c.shape and self._ctx_ref.dtype == c.dtype and torch.equal(c, self._ctx_ref)
+        if not same:
+            self.set_context(c)
+            self._ctx_ref = c.clone()
+        self._ctx_token = token
+
     def __call__(self, apply_model, params: dict) -> torch.Tensor:
         x = params["input"]
         sigma = params["timestep"]
         ctx = params["c"]["c_crossattn"]
         x = x.to(self.device, torch.float32).contiguous()
         sigma = sigma.to(self.device, torch.float32).contiguous()
-        # the reference re-concatenates the context every step (cond_cat, LD.py:2471-2489): re-project only when it changed
-        key = (ctx.data_ptr(), tuple(ctx.shape), ctx._version)
-        if self._ctx_key is None or key != self._ctx_key[0] and not torch.equal(ctx.to(self.device), self._ctx_key[1]):
-            self.set_context(ctx)
-            self._ctx_key = (key, ctx.to(self.device).clone())
+        token = (params["c"].get("transformer_options") or {}).get("ld_ctx_token")
+        self._sync_context(ctx, x.shape[0], x.shape[2], x.shape[3], token)
         return self.forward(x, sigma)
+
+    def cfg_denoise(self, x: torch.Tensor, timestep: torch.Tensor, ctx: torch.Tensor, cond_scale: float, token=None,
+                    use_graph: bool = True) -> torch.Tensor:
+        """One classifier-free-guided step (sampling_function, LD.py:2609-2626) through a cached, hipGraph-captured
+        `pipeline.CFGDenoiser`: ctx is the [uncond.., cond..] batch (2B rows), x [B,4,h,w], timestep [B] (sigma) on the device.
+        This is what `KSampler2.sample` reaches through `sampling.sampling_function`; the reference's counterpart is the
+        CUDA-graph option of its stable-fast patch (LD.py:9902-9946)."""
+        from .pipeline import CFGDenoiser
+        b, _, h, w = x.shape
+        x = x.to(self.device, torch.float32)
+        self._sync_context(ctx, 2 * b, h, w, token)
+        key = (b, h, w, float(cond_scale), bool(use_graph))
+        d = self._denoisers.get(key)
+        if d is None:
+            if len(self._denoisers) >= 4:                      # a few shapes per session (txt2img + hires pass); drop the oldest
+                self._denoisers.pop(next(iter(self._denoisers)))
+            d = self._denoisers[key] = CFGDenoiser(self, b, h, w, cond_scale, use_graph=use_graph)
+        return d.run(x, timestep.to(self.device, torch.float32)).clone()   # samplers keep `denoised` across steps (old_denoised)
 
     def to(self, device):
         return self
@@ -177,7 +235,16 @@ class MI355XVAE:
             check(lib().ld_vae_create(C.byref(c), C.byref(self._h)), "ld_vae_create")
             _load_params(self._h, lib().ld_vae_param_count, lib().ld_vae_param_info, lib().ld_vae_load_param, weights,
                          self.device, ("", "first_stage_model."))
-            check(lib().ld_vae_reserve(self._h, max_batch, max_hw[0], max_hw[1]), "ld_vae_reserve")
+        self._reserved = (0, 0, 0)
+        self._ensure(max_batch, max_hw[0], max_hw[1])
+
+    def _ensure(self, b: int, h: int, w: int) -> None:
+        """Grow the workspace when a call exceeds the plan (batch or latent size), e.g. the 1024^2 decode of a hires pass."""
+        mb, mh, mw = self._reserved
+        if b > mb or h > mh or w > mw:
+            self._reserved = (max(b, mb), max(h, mh), max(w, mw))
+            with torch.cuda.device(self.device):
+                check(lib().ld_vae_reserve(self._h, *self._reserved), "ld_vae_reserve")
 
     def __del__(self):
         try:
@@ -202,6 +269,7 @@ class MI355XVAE:
     def decode_device(self, z: torch.Tensor) -> torch.Tensor:
         z = z.to(self.device, torch.float32).contiguous()
         b, _, h, w = z.shape
+        self._ensure(b, h, w)
         out = torch.empty(b, 8 * h, 8 * w, self.cfg["out_ch"], dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             check(lib().ld_vae_decode(self._h, z.data_ptr(), out.data_ptr(), b, h, w, _stream()), "ld_vae_decode")
@@ -222,6 +290,7 @@ class MI355XVAE:
         h, w = H // 8, W // 8
         if h * 8 != H or w * 8 != W:
             raise ValueError("image sides must be multiples of 8")
+        self._ensure(b, h, w)
         out = torch.empty(b, 2 * self.cfg["z_channels"], h, w, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             check(lib().ld_vae_encode(self._h, px.data_ptr(), out.data_ptr(), b, h, w, _stream()), "ld_vae_encode")

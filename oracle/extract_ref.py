@@ -66,11 +66,15 @@ _DEFS = {
     "forward_timestep_embed1", "Upsample1", "Downsample1", "ResBlock1", "apply_control1", "UNetModel1",
     # model wrappers (LD.py:5779-5976)
     "ModelType", "model_sampling", "BaseModel", "BASE", "sm_SD15",
+    # LoRA ingestion (LD.py:232-394, 401-426, 538-629, 1986-2010, 6203-6219)
+    "unet_to_diffusers", "set_attr_param", "copy_to_param", "load_lora", "model_lora_keys_clip", "model_lora_keys_unet",
+    "cast_to_device", "is_intel_xpu",
     # node API (LD.py:6573-6725)
     "EmptyLatentImage", "LatentUpscale", "common_ksampler", "KSampler2",
 }
 _ASSIGNS = {"ops", "oai_ops", "ae_ops", "ACTIVATIONS", "_ATTN_PRECISION", "KSAMPLER_NAMES",
-            "SCHEDULER_NAMES", "SAMPLER_NAMES", "PROGRESS_BAR_ENABLED"}
+            "SCHEDULER_NAMES", "SAMPLER_NAMES", "PROGRESS_BAR_ENABLED",
+            "UNET_MAP_ATTENTIONS", "TRANSFORMER_BLOCKS", "UNET_MAP_RESNET", "UNET_MAP_BASIC", "LORA_CLIP_MAP"}
 
 
 class _NullBar:

@@ -297,7 +297,114 @@ def g_bislerp():
     save("bislerp", x=x, y2x=ref.bislerp(x, 12, 16), y_odd=ref.bislerp(x, 9, 11))
 
 
+# ------------------------------------------------------------------ 8. full-size goldens at the sizes of BASELINE configs #3 / #5
+def g_configs():
+    """SD1.5 UNet at 128x128 latents (hires-fix, config #5) and the SD1.5 VAE decoder at 64x64 / 128x128 latents
+    (512^2 / 1024^2 images).  The UNet tensors are small enough to store whole; images are stored subsampled plus a
+    full-resolution crop and the moments."""
+    cfg = W.sd15_unet_config()
+    model, _ = build_ref_model(cfg)
+    ms = model.model_sampling
+    x = rnd((2, 4, 128, 128), 81, 1.5)
+    sigma = torch.tensor([1.2768, 0.4])                # hires-fix starts at sigma 1.2768 (normal-10 @ denoise 0.45)
+    ctx = rnd((2, 77, cfg["context_dim"]), 82)
+    eps = model.diffusion_model(ms.calculate_input(sigma, x), ms.timestep(sigma).float(), context=ctx, transformer_options={})
+    den = model.apply_model(x, sigma, c_crossattn=ctx, transformer_options={})
+    save("unet_sd15_128x128", x=x, sigma=sigma, ctx=ctx, eps=eps, denoised=den)
+    del model
+    vcfg = W.sd15_vae_config()
+    dec = ref.Decoder(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=vcfg["ch"],
+                      ch_mult=vcfg["ch_mult"], num_res_blocks=vcfg["num_res_blocks"], attn_resolutions=[], dropout=0.0)
+    eng = ref.AutoencodingEngine(None, dec, None)
+    sd = eng.state_dict()
+    eng.load_state_dict({k: W.synth_tensor(k, tuple(v.shape)) for k, v in sd.items() if not k.startswith("quant_conv")}, strict=False)
+    for hw, sub in ((64, 4), (128, 8)):
+        z = rnd((1, 4, hw, hw), 83 + hw, 1.0 / 0.18215 * 0.2)
+        img = torch.clamp((eng.decode(z) + 1.0) / 2.0, 0.0, 1.0).movedim(1, -1)
+        c0 = 8 * hw // 2 - 37                           # a crop that straddles the image centre, all pixels
+        save(f"vae_sd15_{hw}x{hw}", z=z, img_sub=img[:, ::sub, ::sub], crop=img[:, c0:c0 + 96, c0:c0 + 96], crop_at=np.array([c0, c0]),
+             mean=img.mean(), std=img.std())
+
+
+# ------------------------------------------------------------------ 9. LoRA ingestion through the reference's own key maps + patcher
+def lora_fixture():
+    """A small kohya-format LoRA for the tiny UNet + tiny CLIP, keyed the ways real files are keyed (LD.py:577-629):
+    ldm-flattened names, diffusers-flattened names (what kohya writes for SD1.x), a diffusers-native `unet.` key, a 3x3 conv
+    pair, `lora_te_` text-encoder keys; some with `.alpha`, some without; plus one key no model has."""
+    ucfg = W.tiny_unet_config()
+    mc = ucfg["model_channels"]
+    c1 = mc * ucfg["channel_mult"][1]
+    pairs = {   # name -> (out, in, conv k, alpha or None)
+        "lora_unet_input_blocks_1_1_transformer_blocks_0_attn1_to_q": (mc, mc, 1, 2.0),
+        "lora_unet_down_blocks_0_attentions_1_transformer_blocks_0_attn2_to_k": (mc, ucfg["context_dim"], 1, None),
+        "lora_unet_down_blocks_1_attentions_0_transformer_blocks_0_ff_net_0_proj": (8 * c1, c1, 1, 4.0),
+        "lora_unet_mid_block_attentions_0_proj_in": (None, None, 1, 1.0),        # sizes filled from the model below
+        "lora_unet_up_blocks_1_attentions_2_transformer_blocks_0_attn1_to_out_0": (None, None, 1, 3.0),
+        "lora_unet_down_blocks_0_resnets_0_conv1": (mc, mc, 3, 8.0),
+        "lora_unet_up_blocks_0_resnets_1_time_emb_proj": (None, None, 1, None),
+        "unet.down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor.to_v": (mc, mc, 1, 1.0),
+        "lora_te_text_model_encoder_layers_0_self_attn_q_proj": ("clip", "clip", 1, 2.0),
+        "lora_te_text_model_encoder_layers_1_mlp_fc1": ("clip_fc1", "clip", 1, None),
+        "lora_unet_not_a_layer_of_this_model": (mc, mc, 1, 1.0),
+    }
+    return pairs
+
+
+def g_lora():
+    ucfg, ccfg = W.tiny_unet_config(), W.tiny_clip_config()
+    model, patcher = build_ref_model(ucfg)
+    key_map = ref.model_lora_keys_unet(model, {})
+    class ClipWrap(torch.nn.Module):          # state-dict prefix of the reference's SD1ClipModel: clip_l.transformer.* (LD.py:560-575)
+        def __init__(self, tm):
+            super().__init__()
+            self.clip_l = torch.nn.Module()
+            self.clip_l.transformer = tm
+    tm = ref.CLIPTextModel(ccfg, torch.float32, None, ref.manual_cast)
+    csd = tm.state_dict()
+    tm.load_state_dict({k: W.synth_tensor(k, tuple(v.shape)) for k, v in csd.items() if k != "text_projection.weight"}, strict=False)
+    cw = ClipWrap(tm)
+    key_map = ref.model_lora_keys_clip(cw, key_map)
+    msd, wsd = model.state_dict(), cw.state_dict()
+    rank = 4
+    lora, seed = {}, 900
+    for name, (o, i, k, alpha) in lora_fixture().items():
+        tgt = key_map.get(name)
+        if tgt is not None:
+            wt = msd[tgt] if tgt in msd else wsd[tgt]
+            o, i = wt.shape[0], wt.shape[1]
+        up = rnd((o, rank) if k == 1 else (o, rank, 1, 1), seed, 0.3)
+        down = rnd((rank, i) if k == 1 else (rank, i, 3, 3), seed + 1, 0.3)
+        seed += 2
+        lora[name + ".lora_up.weight"], lora[name + ".lora_down.weight"] = up, down
+        if alpha is not None:
+            lora[name + ".alpha"] = torch.tensor(alpha)
+    loaded = ref.load_lora(lora, key_map)
+    p2 = patcher.clone()
+    ku = p2.add_patches(loaded, 0.8)
+    cp = ref.ModelPatcher(cw, torch.device("cpu"), torch.device("cpu"))
+    kc = cp.add_patches(loaded, 0.6)
+    p2.patch_model()
+    cp.patch_model()
+    x, sigma, ctx = rnd((2, 4, 16, 16), 931, 3.0), torch.tensor([2.5, 0.7]), rnd((2, 77, ucfg["context_dim"]), 932)
+    den = model.apply_model(x, sigma, c_crossattn=ctx, transformer_options={})
+    g = torch.Generator().manual_seed(933)
+    toks = torch.randint(1000, 40000, (1, 77), generator=g)
+    toks[:, 0] = 49406
+    toks[0, 12:] = 49407
+    _, inter, _, _ = tm(toks, None, intermediate_output=-2, final_layer_norm_intermediate=True)
+    out = {"lora::" + k: v for k, v in lora.items()}
+    save("lora_tiny", x=x, sigma=sigma, ctx=ctx, denoised=den, tokens=toks, clip_inter_m2=inter,
+         patched_unet_keys=np.array(sorted(ku)), patched_clip_keys=np.array(sorted(kc)),
+         w_attn1_to_q=model.state_dict()["diffusion_model.input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight"],
+         w_conv1=model.state_dict()["diffusion_model.input_blocks.1.0.in_layers.2.weight"], **out)
+    # the diffusers -> ldm name map itself, for the tiny and the SD1.5 layouts (LD.py:302-394)
+    maps = {"tiny": ref.unet_to_diffusers(ref_unet_config(ucfg)), "sd15": ref.unet_to_diffusers(ref_unet_config(W.sd15_unet_config()))}
+    with open(os.path.join(OUT, "unet_to_diffusers.json"), "w") as f:
+        json.dump({k: dict(sorted(v.items())) for k, v in maps.items()}, f)
+    print("wrote unet_to_diffusers.json", {k: len(v) for k, v in maps.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "blocks", "unets", "samplers", "vae", "vae_enc", "clip", "tokens", "bislerp"]
+    which = sys.argv[1:] or ["schedules", "blocks", "unets", "samplers", "vae", "vae_enc", "clip", "tokens", "bislerp", "configs", "lora"]
     for n in which:
         globals()["g_" + n]()

@@ -17,7 +17,7 @@ def pytest_configure(config):
 
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
-        return {k: torch.from_numpy(z[k]) for k in z.files}
+        return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiub" else z[k]) for k in z.files}
 
 
 @pytest.fixture(scope="session")

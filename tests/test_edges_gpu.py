@@ -76,13 +76,19 @@ def test_error_statuses(unet):
     with pytest.raises(LDError) as e:                       # larger than the reserved workspace
         fresh.forward(torch.randn(2, 4, 32, 32, device=DEV), s)
     assert e.value.status == ERR_SHAPE
-    with pytest.raises(LDError) as e:                       # more context tokens than reserved
-        fresh.set_context(torch.randn(2, 154, 64))
-    assert e.value.status == ERR_SHAPE
-    with pytest.raises(LDError):                            # more samples than reserved
-        fresh.set_context(torch.randn(3, 77, 64))
+    import ctypes as C
+    from lightdiffusion_amd._lib import F32, lib
+    big = torch.randn(2, 154, 64, device=DEV)
+    # the C ABI refuses more context tokens / samples than reserved ...
+    assert lib().ld_unet_set_context(fresh._h, big.data_ptr(), F32, 2, 154, torch.cuda.current_stream().cuda_stream) == ERR_SHAPE
+    assert lib().ld_unet_set_context(fresh._h, big.data_ptr(), F32, 3, 77, torch.cuda.current_stream().cuda_stream) == ERR_SHAPE
     y = fresh.forward(x, s)                                 # the handle is still usable after refused calls
     assert torch.isfinite(y).all()
+    # ... while the host wrapper grows the plan instead, like the reference (any number of 77-token chunks, any batch)
+    epoch = fresh.reserve_epoch
+    fresh.set_context(torch.randn(3, 154, 64))
+    assert fresh.reserve_epoch == epoch + 1
+    assert torch.isfinite(fresh.forward(torch.randn(3, 4, 8, 8, device=DEV), torch.ones(3, device=DEV))).all()
     with pytest.raises(KeyError):                           # a checkpoint that lacks a parameter is rejected at load
         from lightdiffusion_amd.unet import MI355XUNet
         MI355XUNet(W.tiny_unet_config(), {"input_blocks.0.0.weight": torch.zeros(64, 4, 3, 3)})

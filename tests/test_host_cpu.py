@@ -66,14 +66,6 @@ def test_clip_text_model_and_weight_lerp():
         clip.tokenize("needs a tokenizer")
 
 
-def test_bislerp_matches_reference():
-    from lightdiffusion_amd.nodes import LatentUpscale, bislerp
-    g = load_golden("bislerp")
-    assert rel_l2(bislerp(g["x"], 12, 16), g["y2x"]) < 2e-6 and rel_l2(bislerp(g["x"], 9, 11), g["y_odd"]) < 2e-6
-    up = LatentUpscale().upscale({"samples": torch.randn(1, 4, 8, 8)}, "bislerp", 128, 128)[0]["samples"]
-    assert up.shape == (1, 4, 16, 16)
-
-
 def test_node_surface_shapes_and_errors():
     from lightdiffusion_amd import nodes, sampling
     lat = nodes.EmptyLatentImage().generate(512, 768, 3)[0]["samples"]
@@ -133,6 +125,82 @@ def test_world_size_2_gloo():
     assert [r[2] for r in res] == [(0, 3), (3, 5)]
 
 
+# ------------------------------------------------------------------ the composed sharded entry (config #4) over gloo
+class _StubCLIP:
+    def tokenize(self, text):
+        return text
+
+    def encode_from_tokens(self, tokens, return_pooled=False):
+        gen = torch.Generator().manual_seed(len(tokens) + 11)
+        return torch.randn(1, 77 * (2 if len(tokens) > 10 else 1), 16, generator=gen)
+
+
+class _StubModel:
+    load_device = torch.device("cpu")
+    model_options = {}
+
+    def get_model_object(self, name):
+        from lightdiffusion_amd import sampling as S
+        return S.ModelSampling()
+
+
+class _StubVAE:
+    def decode(self, samples):
+        return samples.permute(0, 2, 3, 1)[..., :3].contiguous()
+
+
+def _stub_denoise(x, sigma, ctx):
+    """row-wise toy denoiser that depends on the conditioning (so a wrong broadcast shows)"""
+    return x * (1.0 / (1.0 + sigma.view(-1, 1, 1, 1) ** 2)) + 0.01 * ctx.mean()
+
+
+def _run_sharded(global_batch):
+    """txt2img_sharded with the device sampler loop replaced by the oracle's Euler-a (test seam `run_sampler`)."""
+    from lightdiffusion_amd import nodes
+    from lightdiffusion_amd import sampling as S
+    from oracle import sd15_ref as O
+
+    def run_sampler(noise, latent, pos, neg, sigmas, extra):
+        ms = S.ModelSampling()
+        x = ms.noise_scaling(sigmas[0], noise, latent, True)
+        ctx = torch.cat([neg[0][0], pos[0][0][:, :77]])
+        return O.sample_euler_ancestral(lambda xx, ss: _stub_denoise(xx, ss, ctx), x, [float(s) for s in sigmas],
+                                        noise_sampler=extra["noise_sampler"])
+
+    return nodes.txt2img_sharded(_StubModel(), _StubCLIP(), _StubVAE(), "a long prompt, two chunks", "", width=64, height=48,
+                                 global_batch=global_batch, seed=321, steps=5, run_sampler=run_sampler)
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from lightdiffusion_amd import dist as D
+    D.init("gloo")
+    torch.manual_seed(1000 + rank)           # ranks start from different global-generator states: the entry must not depend on them
+    out = _run_sharded(5)
+    q.put((rank, None if out is None else out.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_txt2img_sharded_world_2_equals_single_process():
+    """Config #4's call order (broadcast -> shard -> full-batch noise rows -> per-rank loop -> gather) on 2 gloo ranks reproduces
+    the single-process Euler-a result row for row (uneven split 3 + 2; initial noise and every ancestral draw sliced)."""
+    single = _run_sharded(5)
+    assert single.shape == (5, 6, 8, 3)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 137) % 500
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res[1] is None and res[0].shape == single.shape
+    assert torch.equal(res[0], single)
+
+
 def _synthetic_checkpoint(tiny=True):
     ucfg, vcfg, ccfg = W.tiny_unet_config(), W.tiny_vae_config(), W.tiny_clip_config()
     sd = {}
@@ -158,6 +226,38 @@ def test_checkpoint_config_detection_and_lora_merge():
     up, down = torch.randn(64, 4), torch.randn(4, 64)
     name = "lora_unet_input_blocks_1_1_transformer_blocks_0_attn1_to_q"
     n = CK.merge_lora(sd, {name + ".lora_up.weight": up, name + ".lora_down.weight": down, name + ".alpha": torch.tensor(2.0)}, 0.5)
-    assert n == 1 and torch.allclose(sd[key].float(), before + 0.5 * (2.0 / 4) * (up @ down), atol=2e-3)
+    assert n == 1 and n.unet == 1 and n.clip == 0 and torch.allclose(sd[key].float(), before + 0.5 * (2.0 / 4) * (up @ down), atol=2e-3)
     with pytest.raises(ValueError):
         CK.detect_unet_config({"foo": torch.zeros(1)})
+
+
+def _lora_from_golden(g):
+    return {k[len("lora::"):]: v for k, v in g.items() if k.startswith("lora::")}
+
+
+def test_lora_key_maps_and_merge_match_reference():
+    """f3: the diffusers -> ldm parameter map against the reference's `unet_to_diffusers` table (tiny and SD1.5 layouts), and a
+    LoRA keyed the ways real files are keyed (kohya ldm / kohya diffusers / diffusers-native / conv / lora_te) merged into a
+    checkpoint against weights patched by the reference's own ModelPatcher (oracle/make_golden.py `lora`)."""
+    import warnings
+    from lightdiffusion_amd import checkpoint as CK
+    ref = json.load(open(os.path.join(GOLDEN, "unet_to_diffusers.json")))
+    for tag, cfg in (("tiny", W.tiny_unet_config()), ("sd15", W.sd15_unet_config())):
+        keys = [CK.UNET_PREFIX + k for k in W.unet_param_shapes(cfg)]
+        have = {k[len(CK.UNET_PREFIX):] for k in keys}
+        assert CK.unet_to_diffusers(keys, cfg["num_res_blocks"]) == {k: v for k, v in ref[tag].items() if v in have}
+    g = load_golden("lora_tiny")
+    lora = _lora_from_golden(g)
+    sd, ucfg, vcfg, ccfg = _synthetic_checkpoint()
+    sd.update({"model.diffusion_model." + k: v for k, v in W.synth_state_dict(W.unet_param_shapes(ucfg)).items()})   # fp32 base weights
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        res = CK.merge_lora(sd, lora, 0.8, 0.6)
+    assert (res.unet, res.clip) == (len(g["patched_unet_keys"]), len(g["patched_clip_keys"])) == (8, 2)
+    assert res.unmatched == ("lora_unet_not_a_layer_of_this_model",) and any("match no layer" in str(w.message) for w in wlist)
+    P = CK.UNET_PREFIX
+    assert torch.allclose(sd[P + "input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight"], g["w_attn1_to_q"], atol=1e-6)
+    assert torch.allclose(sd[P + "input_blocks.1.0.in_layers.2.weight"], g["w_conv1"], atol=1e-6)          # 3x3 conv pair
+    want = {"model." + str(k) for k in g["patched_unet_keys"]}
+    km = CK.lora_key_map(sd)
+    assert {km[m] for m in {k[:-len(".lora_up.weight")] for k in lora if k.endswith(".lora_up.weight")} if m in km and km[m].startswith(P)} == want

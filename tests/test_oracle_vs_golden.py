@@ -215,3 +215,15 @@ def test_vae_encode(tag):
     assert rel_l2(m, g["moments"]) < 2e-5
     torch.manual_seed(58)
     assert rel_l2(O.vae_sample(m), g["z_seed58"]) < 2e-5
+
+
+def test_config_size_goldens():
+    """The oracle at the size of BASELINE config #2's image (oracle/make_golden.py `configs`): SD1.5 VAE decoder at 64x64 latents
+    (512^2).  The 128x128-latent UNet and the 1024^2 decode goldens are compared with the HIP path directly on the GPU
+    (tests/test_configs_gpu.py): the restatement needs minutes of CPU at those sizes."""
+    g = load_golden("vae_sd15_64x64")
+    cfg = W.sd15_vae_config()
+    y = O.vae_decode(W.synth_state_dict(W.vae_decoder_param_shapes(cfg)), cfg, g["z"])
+    c0 = int(g["crop_at"][0])
+    assert float((y[:, ::4, ::4] - g["img_sub"]).abs().max()) < 5e-5 and float((y[:, c0:c0 + 96, c0:c0 + 96] - g["crop"]).abs().max()) < 5e-5
+    assert abs(float(y.mean() - g["mean"])) < 1e-5
