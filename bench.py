@@ -1,25 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py — UNet denoise steps/sec at 512x512 on N MI355X (BASELINE.json metric).
+"""bench.py — UNet denoise steps/sec at 512x512 (batch 8 and batch 1) on N MI355X (BASELINE.json metric).
 
 A "step" is one sampler iteration = one classifier-free-guided UNet forward on 2B samples ([uncond, cond], LD.py:2515)
 + the guidance mix + the sampler update, on synthetic latents with random-init SD1.5 weights (no checkpoints offline).
-Default workload = BASELINE.json configs[1]: SD1.5 512x512, DPM++ 2M (dpmpp_2m_sde eta=0) / karras-20, batch 1, fp16
-storage with fp32 accumulation.  `--batch 8 --sampler euler_ancestral` is configs[2].
-Multi-GPU (torchrun, one rank per GPU): each rank holds a weight replica and runs its own B-image loop (weak scaling);
-the only collective is the RCCL broadcast of the CLIP conditioning before the loop.
+What is timed is the PRODUCT loop: `sampling.sample()` -> `KSAMPLER.sample` -> `sample_euler_ancestral` / `sample_dpmpp_2m_sde`
+-> `CFGGuider` -> `sampling_function` -> the cached hipGraph denoiser (the call stack `KSampler2.sample` runs), in whole
+sampler passes until exactly K steps have been taken.
 
+One invocation reports
+  * headline `value`: BASELINE configs[2] — SD1.5 512x512, Euler-a / normal-30, batch 8 per GPU (UNet batch 16);
+  * `batch1`: BASELINE configs[1] — DPM++ 2M (dpmpp_2m_sde eta=0) / karras-20, batch 1;
+  * (N = 1 only) `hires`: configs[4] — the 128x128-latent Euler-a step at batch 4 and the 1024^2 VAE decode;
+    `images_per_s_e2e`: 20-step txt2img at batch 8 including the VAE decode; `cpu_baseline`: the oracle on the host cores.
+each with its own `roofline` for the dominant kernel instantiation (HIP events around every launch, on the launch stream).
+
+Multi-GPU: one rank per GPU (torchrun, or `--gpus N` alone, which starts N rank processes itself), a weight replica and an
+independent B-image loop per rank (weak scaling); the only collective is the RCCL broadcast of the conditioning.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+MFMA_PEAK_F16 = 2.5e15      # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -34,27 +46,43 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("LD_BENCH_CPU_THREADS", "16"))))
 
 
-MFMA_PEAK_F16 = 2.5e15      # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-HBM_PEAK = 8.0e12
+def spawn_ranks(n, argv):
+    """`--gpus N` without a torchrun environment: start N fresh rank processes (this process never touches the GPU)."""
+    port = 29400 + os.getpid() % 400
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    sys.exit(rc)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU (UNet batch is 2x this under CFG)")
-    ap.add_argument("--sampler", default=None, choices=[None, "dpmpp_2m", "euler_ancestral"])
-    ap.add_argument("--latent", type=int, default=64, help="latent side (64 = 512x512 px)")
+    ap.add_argument("--steps", type=int, default=150, help="timed steps K of the headline (batch 8) and of the batch-1 run")
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU of the headline run (UNet batch is 2x this under CFG)")
     ap.add_argument("--cfg", type=float, default=7.0)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip batch-1 / hires / e2e / cpu baseline (profiling runs)")
+    ap.add_argument("--only", default=None, choices=[None, "batch8", "batch1", "hires"], help="time just one workload (profiling runs)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}, "
+                         f"or pass --gpus alone and let bench.py start the ranks")
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -70,22 +98,22 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from lightdiffusion_amd import ops, sampling
+    from lightdiffusion_amd import nodes, sampling
     from lightdiffusion_amd import weights as W
-    from lightdiffusion_amd.pipeline import CFGDenoiser
-    from lightdiffusion_amd.unet import synthetic_unet
+    from lightdiffusion_amd.unet import synthetic_unet, synthetic_vae
 
-    B, L = args.batch, args.latent
-    sampler = args.sampler or ("dpmpp_2m" if B == 1 else "euler_ancestral")
     cfg = W.sd15_unet_config()
-    t0 = time.time()
     torch.set_num_threads(host_cores())
+    t0 = time.time()
     log(f"rank {rank}/{world}: building SD1.5 UNet (synthetic weights) on {dev}")
-    unet = synthetic_unet(cfg, max_batch=2 * B, max_hw=(L, L), device=dev)
+    unet = synthetic_unet(cfg, max_batch=2 * args.batch, max_hw=(64, 64), device=dev)
     t_load = time.time() - t0
     log(f"weights resident in {t_load:.1f}s: {unet.weight_bytes / 2**20:.0f} MiB weights, {unet.workspace_bytes / 2**20:.0f} MiB workspace")
+    model = nodes._attach(unet, dev)                      # ModelPatcher + set_model_unet_function_wrapper: the reference's plugin seam
+    if args.no_graph:
+        model.model_options["ld_use_graph"] = False
 
-    # ---- conditioning: rank 0 "encodes", RCCL broadcast over xGMI to the other ranks (the only collective)
+    # ---- conditioning: rank 0 "encodes", ONE RCCL broadcast over xGMI to the other ranks (the only collective)
     g = torch.Generator().manual_seed(1234)
     cond2 = torch.randn(2, 77, cfg["context_dim"], generator=g).to(dev) if rank == 0 else torch.empty(2, 77, cfg["context_dim"], device=dev)
     t_bcast = 0.0
@@ -95,101 +123,167 @@ def main():
         dist.broadcast(cond2, src=0)
         torch.cuda.synchronize()
         t_bcast = time.time() - tb
-    den_fn = CFGDenoiser(unet, B, L, L, args.cfg, use_graph=not args.no_graph)
-    den_fn.set_context(cond2[0:1], cond2[1:2])
-
-    # ---- schedule + per-step update coefficients (host scalars, as the reference computes them)
+    cond_cpu = cond2.cpu()
+    pos, neg = [[cond_cpu[1:2], {"pooled_output": None}]], [[cond_cpu[0:1], {"pooled_output": None}]]
     ms = sampling.ModelSampling()
-    if sampler == "dpmpp_2m":
-        sig = sampling.calculate_sigmas(ms, "karras", 20)
-    else:
-        sig = sampling.calculate_sigmas(ms, "normal", 30)
-    nstep = len(sig) - 2                       # positions with sigma_next > 0 (the last position is just x = denoised)
-    gen = torch.Generator().manual_seed(rank)
-    x = (torch.randn(B, 4, L, L, generator=gen) * float(sig[0])).to(dev)
-    noise = torch.randn(B, 4, L, L, generator=gen).to(dev)
-    old = torch.zeros_like(x)
-    state = {"h_last": None}
-
-    def step(i):
-        p = i % nstep
-        if p == 0 and i > 0:
-            ops.axpby_(x, 0.0, noise, float(sig[0]))          # wrap: re-noise to sigma_max so the data stays in range
-            state["h_last"] = None
-        s, sn = sig[p], sig[p + 1]
-        den = den_fn(x, float(s))
-        if sampler == "euler_ancestral":
-            sd_, su = sampling.get_ancestral_step(float(s), float(sn))
-            r = (sd_ - float(s)) / float(s)
-            ops.axpby_(x, 1.0 + r, den, -r, noise, su)
-        else:
-            h = (-sn.log()) - (-s.log())
-            a, c1 = float(sn / s), float((-h).expm1().neg())
-            if state["h_last"] is None:
-                ops.axpby_(x, a, den, c1)
-            else:
-                k = float(0.5 * (-h).expm1().neg() * (h / state["h_last"]))
-                ops.axpby_(x, a, den, c1 + k, old, -k)
-            old.copy_(den)
-            state["h_last"] = h
+    traffic_db = {}
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tp):
+        traffic_db = json.load(open(tp))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    log("warm-up done (graph captured)" if not args.no_graph else "warm-up done (eager)")
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.barrier()
-        elapsed = float(t.item())
-    finite = bool(torch.isfinite(x).all())
-    log(f"timed {args.steps} steps in {elapsed:.3f}s -> {world * args.steps / elapsed:.2f} steps/s")
+    def run_workload(tag, B, L, sampler, scheduler, sched_steps, denoise, K, Wm, cfg_scale):
+        """Time exactly K steps of the product sampler loop (whole passes over the schedule, then a partial one)."""
+        ks = sampling.KSampler1(model, steps=sched_steps, device=dev, sampler=sampler, scheduler=scheduler, denoise=denoise,
+                                model_options=model.model_options)
+        sig = ks.sigmas
+        run_len = len(sig) - 1
+        opts = {"eta": 0.0} if sampler == "dpmpp_2m_sde" else {}
+        gen = torch.Generator().manual_seed(1000 + rank)
+        latent = torch.zeros(B, 4, L, L) if denoise is None else torch.randn(B, 4, L, L, generator=gen) * 0.8
+        noise = torch.randn(B, 4, L, L, generator=gen)
 
-    # ---- per-kernel-class device time: HIP events around every launch of one forward (after the timed region)
-    prof = None
-    for _ in range(3):
-        p = unet.profile(den_fn.x2, den_fn.sigma2)
-        prof = p if prof is None else {k: (prof[k][0] + v[0], v[1], v[2]) for k, v in p.items()}
-    prof = {k: (v[0] / 3.0, v[1], v[2]) for k, v in prof.items()}
-    dom = max(("conv3x3", "gemm", "attention"), key=lambda k: prof[k][0])
-    d_ms, d_fl, d_n = prof[dom]
-    step_flops = unet.last_flops
+        def passes(nsteps):
+            done = 0
+            while done < nsteps:
+                n = min(run_len, nsteps - done)
+                sampling.sample(model, noise, pos, neg, cfg_scale, dev, sampling.ksampler(sampler, opts), sig[: n + 1], model.model_options,
+                                latent_image=latent, seed=rank)
+                done += n
+
+        passes(Wm)
+        barrier()
+        t0 = time.perf_counter()
+        passes(K)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.barrier()
+            elapsed = float(t.item())
+        # repetitions (after the contract's bracket): 5 more brackets of one schedule pass each -> median ms/step
+        reps = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            passes(run_len)
+            torch.cuda.synchronize()
+            reps.append(1e3 * (time.perf_counter() - t1) / run_len)
+        # ---- per-kernel device time: HIP events around every launch of one forward, on the launch stream
+        den = next(iter(d for k, d in unet._denoisers.items() if k[0] == B and k[1] == L))
+        agg = {}
+        cls = None
+        for _ in range(3):
+            c = unet.profile(den.x2, den.sigma2)
+            cls = c if cls is None else {k: (cls[k][0] + v[0], v[1], v[2]) for k, v in c.items()}
+            for name, (msv, fl, nl) in unet.profile_kernels().items():
+                a = agg.get(name, (0.0, fl, nl))
+                agg[name] = (a[0] + msv, fl, nl)
+        agg = {k: (v[0] / 3.0, v[1], v[2]) for k, v in agg.items()}
+        cls = {k: (v[0] / 3.0, v[1], v[2]) for k, v in cls.items()}
+        dom = max((k for k in agg if agg[k][1] > 0), key=lambda k: agg[k][0])
+        d_ms, d_fl, d_n = agg[dom]
+        step_flops = unet.last_flops
+        tr = traffic_db.get(tag, {}).get(dom)
+        res = {
+            "workload": f"SD1.5 512x512 UNet CFG step, {sampler} / {scheduler}-{sched_steps}, batch {B}/GPU (UNet batch {2 * B}), latent {L}x{L}",
+            "steps_per_s": world * K / elapsed, "ms_per_step": 1e3 * elapsed / K, "steps": K,
+            "ms_per_step_median_of_5_passes": statistics.median(reps), "ms_per_step_passes": [round(r, 4) for r in reps],
+            "unet_evals_per_s": world * K * 2 * B / elapsed,
+            "step_tflops": step_flops / 1e12,
+            "mfma_frac_whole_step": step_flops * K / elapsed / MFMA_PEAK_F16,
+            "launches_per_forward": unet.last_launches,
+            "kernel_class_ms_per_forward": {k: round(v[0], 4) for k, v in cls.items()},
+            "kernels_ms_per_forward": {k: [round(v[0], 4), v[2]] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]},
+            "roofline": {"kernel": dom, "bound": "mfma", "achieved": d_fl / (d_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_F16 / 1e12,
+                         "unit": "TFLOP/s", "frac": (d_fl / (d_ms * 1e-3)) / MFMA_PEAK_F16,
+                         "traffic": tr, "launches": d_n, "avg_launch_us": 1e3 * d_ms / max(d_n, 1), "flops_per_launch": d_fl / max(d_n, 1)},
+        }
+        log(f"{tag}: {K} steps in {elapsed:.3f}s -> {res['steps_per_s']:.2f} steps/s ({res['unet_evals_per_s']:.0f} UNet-evals/s); "
+            f"dominant {dom} {res['roofline']['achieved']:.0f} TFLOP/s")
+        return res
+
+    K, Wm = args.steps, args.warmup
+    out_extra = {}
+    head = None
+    if args.only in (None, "batch8"):
+        head = run_workload("batch8", args.batch, 64, "euler_ancestral", "normal", 30, None, K, Wm, args.cfg)
+    if (args.only is None and not args.no_extras) or args.only == "batch1":
+        out_extra["batch1"] = run_workload("batch1", 1, 64, "dpmpp_2m_sde", "karras", 20, None, K, min(Wm, 20), args.cfg)
+    if ((args.only is None and not args.no_extras) and world == 1) or args.only == "hires":
+        # config #5: hires-fix second pass — [4,4,128,128], 10 Euler-a steps from sigma 1.2768 (normal, denoise 0.45, cfg 8) + VAE -> 1024^2
+        out_extra["hires"] = run_workload("hires", 4, 128, "euler_ancestral", "normal", 10, 0.45, 20, 10, 8.0)
+    if head is None:
+        head = out_extra.get("batch1") or out_extra.get("hires")
+
+    if args.only is None and not args.no_extras and world == 1:
+        vae = synthetic_vae(W.sd15_vae_config(), max_batch=args.batch, max_hw=(64, 64), device=dev)
+        lat = torch.randn(args.batch, 4, 64, 64, generator=torch.Generator().manual_seed(5)) * 4.0
+
+        def timed(fn, n=3):
+            fn()
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            return statistics.median(ts)
+
+        t_vae = timed(lambda: vae.decode_device(lat))
+        out_extra["vae_decode_512"] = {"batch": args.batch, "ms": 1e3 * t_vae, "images_per_s": args.batch / t_vae,
+                                       "tflops": vae.last_flops / t_vae / 1e12}
+        # end to end: 20-step DPM++ 2M txt2img at batch B through the node-level sampler + VAE decode (CLIP not included:
+        # the conditioning is synthetic), latents stay on the device between the two
+        ks20 = sampling.KSampler1(model, steps=20, device=dev, sampler="dpmpp_2m_sde", scheduler="karras", denoise=None,
+                                  model_options=model.model_options)
+        z0 = torch.zeros(args.batch, 4, 64, 64)
+        nz = torch.randn(args.batch, 4, 64, 64, generator=torch.Generator().manual_seed(6))
+
+        def e2e():
+            s = sampling.sample(model, nz, pos, neg, args.cfg, dev, sampling.ksampler("dpmpp_2m_sde", {"eta": 0.0}), ks20.sigmas,
+                                model.model_options, latent_image=z0, seed=0)
+            return vae.decode_device(s)
+        t_e2e = timed(e2e)
+        out_extra["images_per_s_e2e"] = {"value": args.batch / t_e2e, "batch": args.batch, "seconds": t_e2e,
+                                         "what": "20-step DPM++ 2M / karras txt2img 512x512 (sampler loop + VAE decode; synthetic conditioning)"}
+        del vae
+        vae = synthetic_vae(W.sd15_vae_config(), max_batch=4, max_hw=(128, 128), device=dev)
+        lat = torch.randn(4, 4, 128, 128, generator=torch.Generator().manual_seed(7)) * 4.0
+        t_v2 = timed(lambda: vae.decode_device(lat), n=2)
+        out_extra["vae_decode_1024"] = {"batch": 4, "ms": 1e3 * t_v2, "images_per_s": 4 / t_v2, "tflops": vae.last_flops / t_v2 / 1e12}
+        del vae
+        torch.cuda.empty_cache()
 
     out = {
         "metric": "UNet denoise steps/sec at 512x512",
-        "value": world * args.steps / elapsed,
+        "value": head["steps_per_s"],
         "unit": "steps/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
+        "n_gpus": world, "steps": head["steps"], "warmup": Wm,
+        "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 (fp32 accumulate)", "data": "synthetic latents + random-init SD1.5 weights",
-        "config": {"workload": f"SD1.5 512x512 UNet CFG step, {sampler}, batch {B}/GPU (UNet batch {2 * B})", "latent": [L, L],
-                   "global_batch": B * world, "parallelism": f"dp{world} (replicas, RCCL cond broadcast)", "hip_graph": not args.no_graph},
-        "unet_evals_per_s": world * args.steps * 2 * B / elapsed,
-        "step_tflops": step_flops / 1e12,
-        "mfma_frac_whole_step": step_flops * args.steps / elapsed / MFMA_PEAK_F16,
-        "launches_per_forward": unet.last_launches,
-        "cond_broadcast_ms": 1e3 * t_bcast,
-        "weights_load_s": t_load, "finite": finite,
-        "kernel_ms_per_forward": {k: round(v[0], 4) for k, v in prof.items()},
-        "roofline": {"kernel": f"gemm3_kernel / gemm4_kernel family, launch class '{dom}'", "bound": "mfma", "achieved": d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0,
-                     "peak": MFMA_PEAK_F16 / 1e12, "unit": "TFLOP/s",
-                     "frac": (d_fl / (d_ms * 1e-3)) / MFMA_PEAK_F16 if d_ms > 0 else 0.0, "traffic": None,
-                     "launches": d_n, "avg_launch_us": 1e3 * d_ms / max(d_n, 1), "flops_per_launch": d_fl / max(d_n, 1)},
+        "config": {"workload": head["workload"], "global_batch": args.batch * world,
+                   "parallelism": f"dp{world} (replicas, RCCL cond broadcast)", "hip_graph": not args.no_graph,
+                   "timed_loop": "lightdiffusion_amd.sampling.sample (product call surface)"},
+        "unet_evals_per_s": head["unet_evals_per_s"],
+        "step_tflops": head["step_tflops"], "mfma_frac_whole_step": head["mfma_frac_whole_step"],
+        "ms_per_step_median_of_5_passes": head["ms_per_step_median_of_5_passes"],
+        "launches_per_forward": head["launches_per_forward"],
+        "cond_broadcast_ms": 1e3 * t_bcast, "weights_load_s": t_load,
+        "kernel_class_ms_per_forward": head["kernel_class_ms_per_forward"], "kernels_ms_per_forward": head["kernels_ms_per_forward"],
+        "roofline": head["roofline"],
     }
+    out.update(out_extra)
 
     # ---- CPU baseline: the oracle (a port of the reference's CPU path) on this host's cores; rank 0, single-GPU runs only
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and args.only is None and not args.no_extras:
         from oracle import sd15_ref as O
         ncpu = host_cores()
         torch.set_num_threads(ncpu)
@@ -197,20 +291,20 @@ def main():
         sd = W.synth_state_dict(W.unet_param_shapes(cfg))
         log("cpu baseline: running")
         oms = O.ModelSampling()
-        xc = torch.randn(1, 4, L, L) * 5.0
-        ctx = cond2.cpu()
+        xc = torch.randn(1, 4, 64, 64) * 5.0
         den_cpu = lambda xx, ss, cc: O.apply_model(sd, cfg, oms, xx, ss, cc)
         with torch.no_grad():
-            O.sampling_function(den_cpu, xc, torch.tensor([5.0]), ctx[1:2], ctx[0:1], args.cfg)        # warm-up
+            O.sampling_function(den_cpu, xc, torch.tensor([5.0]), cond_cpu[1:2], cond_cpu[0:1], args.cfg)        # warm-up
             tc = time.perf_counter()
             for j in range(args.cpu_steps):
-                O.sampling_function(den_cpu, xc, torch.tensor([5.0]), ctx[1:2], ctx[0:1], args.cfg)
+                O.sampling_function(den_cpu, xc, torch.tensor([5.0]), cond_cpu[1:2], cond_cpu[0:1], args.cfg)
                 log(f"cpu baseline: step {j + 1}/{args.cpu_steps}")
             tc = time.perf_counter() - tc
         out["cpu_baseline"] = {"value": args.cpu_steps / tc, "unit": "steps/s", "cores": ncpu, "kind": "port",
-                               "sample": f"{args.cpu_steps} CFG steps at batch 1 (UNet batch 2), 64x64 latent, fp32 torch CPU ops"}
+                               "sample": f"{args.cpu_steps} CFG steps at batch 1 (UNet batch 2), 64x64 latent, fp32 torch CPU ops "
+                                         f"(x8 the work per step at the headline's batch 8)"}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

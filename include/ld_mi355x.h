@@ -74,6 +74,9 @@ int ld_unet_forward(ld_unet* u, const float* x, const float* sigma, float* out, 
  * 0 conv3x3 (implicit GEMM)  1 linear / 1x1 GEMM  2 attention  3 GroupNorm  4 LayerNorm  5 misc.  Synchronises the stream. */
 int ld_unet_profile(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, void* stream, double ms[6],
                     double flops[6], int launches[6]);
+/* per kernel INSTANTIATION (the names rocprofv3 --kernel-trace lists, abbreviated) of the last ld_unet_profile call:
+ * one text line "name<TAB>launches<TAB>total ms<TAB>algorithmic FLOPs" each, NUL-terminated.  LD_ERR_ARG if buf is too small. */
+int ld_unet_profile_kernels(const ld_unet* u, char* buf, size_t buf_bytes);
 /* number of kernel launches of the last forward, and algorithmic FLOPs of it (2*M*N*K over every contraction) */
 int ld_unet_last_launches(const ld_unet* u);
 double ld_unet_last_flops(const ld_unet* u);

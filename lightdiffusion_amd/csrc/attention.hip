@@ -1,22 +1,30 @@
-// Flash-style attention for the UNet's self / cross attention (softmax(QK^T/sqrt(d)) V, no mask — LD.py:3966-3978).
+// Flash-style attention for the UNet's self / cross attention (softmax(QK^T/sqrt(d)) V, no mask — LD.py:3966-3978) and the
+// CLIP text model's causal attention (LD.py:4440-4446).
 //
-// Two kernels: flash_attn2_kernel (further down; the one launched) and flash_attn_kernel (the first version, kept for A/B under
-// LD_ATTN_V1=1).  They share the register-level design; what differs is the tile pipeline and the softmax bookkeeping.
-//
-// gfx950 design (32x32x16 f16 MFMA, wave = 64) — flash_attn_kernel:
-//  * one workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries.
+// gfx950 design (32x32x16 f16 MFMA, wave = 64) — flash_attn2_kernel:
+//  * one workgroup = NW (4 or 8) waves = 32*NW queries of one (batch, head); each wave owns 32 queries.
 //  * S^T = K·Q^T ("swapped" product): the query sits on the MFMA lane, so a lane's 16 accumulator registers are
 //    16 keys of ONE query and the online softmax needs no cross-lane traffic except one half-wave exchange.
 //  * the S^T accumulator tile is fed straight back as the B operand of O^T += V^T·P^T (cdna guide §3 "accumulator
 //    tile as the next MFMA's operand").  K rows are read through the bit-2<->bit-3 row permutation so that the
 //    permuted k-order of that trick becomes the natural key order and V^T fragments are single 16-byte LDS reads.
-//  * V arrives already transposed ([channel][key], produced by a swapped projection GEMM), so both LDS tiles are
-//    filled with plain 16-byte row copies; rows are padded by 16 B -> conflict-free ds_read_b128.
-//  * K/V tiles (64 keys) are prefetched global->registers under the MFMA phase of the previous tile (T14).
-//  * O rescale is skipped (wave-uniform branch) whenever no running max moved — exact, not thresholded.
+//  * V arrives already transposed ([channel][key], produced by a swapped projection GEMM).
+//  * K / V^T tiles (64 keys) go global -> LDS by LDS-DMA (no register staging, no commit stores) into a DOUBLE-buffered
+//    pair, so a tile costs one s_barrier and its loads have a whole tile of MFMA + softmax time to land.
+//  * K tile: dense rows of d halfs (d/8 16-byte chunks); chunk c of row `row` sits at physical chunk c ^ swz(row), with
+//    the XOR width chosen from the row stride so that 8 consecutive rows land in 8 distinct 16-byte slots of a 128-byte
+//    bank line (d=40: stride 80 B needs none; d=80: 1 bit; d=160: 2 bits).  The DMA writes lane-linear, so the swizzle
+//    is applied to the SOURCE address of each lane and to the fragment read alike.
+//  * V^T tile: 32*DV rows of 64 keys (8 chunks), chunk ^= row & 7.  Rows >= d are sourced from a zero page (and the
+//    spare "ones" row from a page of fp16 1.0) every tile: the tile is always whole instructions, nothing to pre-fill.
+//  * a d that is an odd multiple of 8 leaves one pad chunk in the last QK^T k-step; the matching Q fragment is zero and
+//    the pad chunk reads the next row's first chunk (or the zero-filled slack after the last row): 0 * finite = 0.
+//  * lazy softmax reference: O / l are rescaled only when a tile maximum exceeds the running reference by > 8.
 // Head dims: d % 8 == 0, d <= 160 (SD1.5: 40 / 80 / 160).  Template DK = ceil(d/16) k-steps of QK^T.
 #include <cstdlib>
 #include <type_traits>
+
+#include <string>
 
 #include "kernels.h"
 // Ablation builds behind profiles/README.md ("no exp", "no tile sync", "1 of 4 PV MFMAs", "2 of 7 fragment reads"): -DLD_ATT_DBG=1..4.
@@ -29,261 +37,6 @@ namespace {
 
 constexpr int AT_THREADS = 256;
 
-template <int DK, int KT_KEYS, int SMX = 1, int WPS = 1>   // KT_KEYS: keys per LDS tile; SMX: softmax variant (A/B); WPS: min waves per SIMD
-__global__ __launch_bounds__(AT_THREADS, WPS) void flash_attn_kernel(const AttnParams p) {
-    constexpr int DV = (DK + 1) / 2;            // 32-row tiles of O^T
-    constexpr bool ONES = (DK & 1) != 0;        // d <= 16*DK < 32*DV: a spare V^T row exists -> row-sum of P by MFMA
-    constexpr int KLD = 16 * DK + 8;            // K tile row stride (halfs)
-    constexpr int VLD = KT_KEYS + 8;            // V^T tile row stride (halfs)
-    constexpr int KCH = KT_KEYS * 2 * DK;       // 16-byte chunks in a (padded-d) K tile
-    constexpr int VCH = 32 * DV * (KT_KEYS / 8); // chunks in a V^T tile
-    constexpr int KIT = (KCH + AT_THREADS - 1) / AT_THREADS;
-    constexpr int VIT = (VCH + AT_THREADS - 1) / AT_THREADS;
-    __shared__ __attribute__((aligned(16))) half_t Ks[KT_KEYS * KLD];
-    __shared__ __attribute__((aligned(16))) half_t Vs[32 * DV * VLD];
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int qblocks = (p.Lq + 127) / 128;
-    const int nblk = qblocks * p.H * p.B;
-    int bid = xcd_remap(blockIdx.x, nblk);
-    const int qb = bid % qblocks;
-    bid /= qblocks;
-    const int head = bid % p.H, b = bid / p.H;
-    const int d = p.d;
-
-    const half_t* Qg = p.Q + (long long)b * p.sQ + head * d;
-    const half_t* Kg = p.K + (long long)b * p.sK + head * d;
-    const half_t* Vg = p.Vt + (long long)b * p.sV + (long long)head * d * p.ldvt;
-
-    // ---- Q fragments (B operand: lane (r,hh) holds Q[q][16*ks + 8*hh .. +7])
-    const int qrow = qb * 128 + wid * 32 + r;
-    half8 qf[DK];
-#pragma unroll
-    for (int ks = 0; ks < DK; ++ks) {
-        const int c = 16 * ks + 8 * hh;
-        qf[ks] = as_half8((qrow < p.Lq && c < d) ? ld16(Qg + (long long)qrow * p.ldq + c) : zero16());
-    }
-
-    // ---- zero the LDS tiles once: padded columns/rows are never overwritten by the tile copies
-    for (int i = tid; i < KT_KEYS * KLD / 8; i += AT_THREADS) st16(Ks + i * 8, zero16());
-    for (int i = tid; i < 32 * DV * VLD / 8; i += AT_THREADS) st16(Vs + i * 8, zero16());
-
-    uint4 rk[KIT], rv[VIT];
-    const int dch = d >> 3;   // real 16-byte chunks per key row
-    // Loader state hoisted out of the tile loop: per-thread source pointers that advance by a constant per tile and
-    // the tile-independent part of each chunk's validity.  Only the ragged LAST tile re-checks keys against Lk
-    // (wave-uniform branch), so the steady state issues bare 16-byte loads.
-    const half_t* kp[KIT];
-    const half_t* vp[VIT];
-    bool kin[KIT], vin[VIT];
-    int krow[KIT], vcol[VIT];
-    bool vones[VIT];
-#pragma unroll
-    for (int i = 0; i < KIT; ++i) {
-        const int q = tid + i * AT_THREADS;
-        const int row = q / (2 * DK), cc = q - row * (2 * DK);
-        krow[i] = row;
-        kin[i] = q < KCH && cc < dch;
-        kp[i] = Kg + (long long)row * p.ldk + cc * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < VIT; ++i) {
-        const int q = tid + i * AT_THREADS;
-        const int row = q / (KT_KEYS / 8), cc = q - row * (KT_KEYS / 8);
-        vcol[i] = cc * 8;
-        vin[i] = q < VCH && row < d;
-        vp[i] = Vg + (long long)row * p.ldvt + cc * 8;
-        // spare row 32*DV-1 := 1.0 (fp16 0x3C00): O^T row 32*DV-1 then accumulates sum_k P[k], the softmax
-        // denominator, on the matrix core instead of 16 VALU adds per tile
-        vones[i] = ONES && row == 32 * DV - 1;
-    }
-    auto fill = [&](int i) {   // what a V^T chunk holds when it is not loaded: the ones row, or zeros
-        const unsigned w = vones[i] ? 0x3C003C00u : 0u;
-        return make_uint4(w, w, w, w);
-    };
-    auto prefetch = [&](int key0) {
-        if (key0 + KT_KEYS <= p.Lk) {          // full tile: no per-key checks
-#pragma unroll
-            for (int i = 0; i < KIT; ++i) rk[i] = kin[i] ? ld16(kp[i]) : zero16();
-#pragma unroll
-            for (int i = 0; i < VIT; ++i) rv[i] = vin[i] ? ld16(vp[i]) : fill(i);
-        } else {
-#pragma unroll
-            for (int i = 0; i < KIT; ++i) rk[i] = (kin[i] && key0 + krow[i] < p.Lk) ? ld16(kp[i]) : zero16();
-#pragma unroll
-            for (int i = 0; i < VIT; ++i) rv[i] = (vin[i] && key0 + vcol[i] < p.Lk) ? ld16(vp[i]) : fill(i);
-        }
-#pragma unroll
-        for (int i = 0; i < KIT; ++i) kp[i] += (long long)KT_KEYS * p.ldk;
-#pragma unroll
-        for (int i = 0; i < VIT; ++i) vp[i] += KT_KEYS;
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < KIT; ++i) {
-            const int q = tid + i * AT_THREADS;
-            const int row = q / (2 * DK), cc = q - row * (2 * DK);
-            if (q < KCH) st16(Ks + row * KLD + cc * 8, rk[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < VIT; ++i) {
-            const int q = tid + i * AT_THREADS;
-            const int row = q / (KT_KEYS / 8), cc = q - row * (KT_KEYS / 8);
-            if (q < VCH) st16(Vs + row * VLD + cc * 8, rv[i]);
-        }
-    };
-
-    f32x16 o[DV];
-#pragma unroll
-    for (int t = 0; t < DV; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const float c2 = p.scale * 1.44269504088896340736f;   // scores are exponentiated in base 2
-
-    // permuted K row for this lane's MFMA row r: swap bits 2 and 3
-    const int prow = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
-
-    const int ntiles = (p.Lk + KT_KEYS - 1) / KT_KEYS;
-    prefetch(0);
-    for (int t = 0; t < ntiles; ++t) {
-        const int key0 = t * KT_KEYS;
-#if LD_ATT_DBG == 2
-        if (t == 0) {
-#endif
-        __syncthreads();   // every wave is done reading the previous tile (and, for t = 0, the zero fill landed)
-        commit();
-        __syncthreads();
-#if LD_ATT_DBG == 2
-        }
-#else
-        if (t + 1 < ntiles) prefetch(key0 + KT_KEYS);
-#endif
-#pragma unroll
-        for (int sub = 0; sub < KT_KEYS / 32; ++sub) {
-            if (key0 + sub * 32 >= p.Lk) break;   // wave-uniform: nothing valid in this half tile
-            f32x16 s;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < DK; ++ks) {
-                const half8 kf = as_half8(ld16(Ks + (sub * 32 + prow) * KLD + 16 * ks + 8 * hh));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
-            }
-            if (p.causal) {                        // causal: key index must not exceed the query index
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    const int key = (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
-                    if (key0 + sub * 32 + key > qrow) s[e] = -INFINITY;
-                }
-            }
-            if (key0 + sub * 32 + 32 > p.Lk) {   // ragged last tile: mask keys >= Lk
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int i = (e & 3) + 8 * (e >> 2) + 4 * hh;                       // MFMA row of this register
-                    const int key = (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);         // key it carries
-                    if (key0 + sub * 32 + key >= p.Lk) s[e] = -INFINITY;
-                }
-            }
-            float mx;
-            if (SMX == 1) {
-                // 16 -> 1 as a tree of 3-input maxima (v_max3_f32): 8 instructions instead of 15
-                mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
-#pragma unroll
-                for (int e = 3; e + 1 < 16; e += 2) mx = fmaxf(fmaxf(mx, s[e]), s[e + 1]);
-                mx = fmaxf(mx, s[15]);
-            } else {
-                mx = s[0];
-#pragma unroll
-                for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float mc = m_new * c2;
-            float psum = 0.f;
-            half8 pf[2];
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-#if LD_ATT_DBG == 1
-                const float p0 = s[e] * c2 - mc, p1 = s[e + 1] * c2 - mc;
-#else
-                const float p0 = __builtin_amdgcn_exp2f(s[e] * c2 - mc);       // raw v_exp_f32: argument <= 0
-                const float p1 = __builtin_amdgcn_exp2f(s[e + 1] * c2 - mc);
-#endif
-                if (!ONES) psum += p0 + p1;
-                // one v_cvt_pkrtz_f16_f32 per pair (instead of 2 cvt + 1 pack).  Round-toward-zero biases P by < 2^-10
-                // relative; numerator and (MFMA row-sum) denominator are built from the same rounded P, so it cancels.
-                if (SMX == 1) {
-                    const half2v h2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(p0, p1));
-                    pf[e >> 3][e & 7] = h2[0];
-                    pf[e >> 3][(e & 7) + 1] = h2[1];
-                } else {
-                    pf[e >> 3][e & 7] = (half_t)p0;
-                    pf[e >> 3][(e & 7) + 1] = (half_t)p1;
-                }
-            }
-            if (__any(m_new > m_run)) {
-                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-                l_run *= alpha;
-#pragma unroll
-                for (int tt = 0; tt < DV; ++tt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[tt][e] *= alpha;
-            }
-            l_run += psum;
-            m_run = m_new;
-#pragma unroll
-            for (int tt = 0; tt < (LD_ATT_DBG == 3 ? 1 : DV); ++tt)
-#pragma unroll
-                for (int k2 = 0; k2 < (LD_ATT_DBG == 3 ? 1 : 2); ++k2) {
-                    const half8 vf = as_half8(ld16(Vs + (tt * 32 + r) * VLD + sub * 32 + 16 * k2 + 8 * hh));
-                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[k2], o[tt], 0, 0, 0);
-                }
-        }
-    }
-
-    float l_tot;
-    if (ONES) {
-        // row 32*DV-1 = tile DV-1, local row 31 = register 15 of the upper half-wave (row = (r&3) + 8*(r>>2) + 4*h)
-        l_tot = __shfl(o[DV - 1][15], 32 + r, 64);
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    }
-    const float inv = 1.0f / l_tot;
-    if (qrow < p.Lq) {
-        half_t* Og = p.O + (long long)b * p.sO + (long long)qrow * p.ldo + head * d;
-#pragma unroll
-        for (int tt = 0; tt < DV; ++tt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int dd = tt * 32 + 8 * g + 4 * hh;
-                if (dd < d) {
-                    half4 h;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[tt][4 * g + e] * inv);
-                    *reinterpret_cast<half4*>(Og + dd) = h;
-                }
-            }
-    }
-}
-
-
-// =====================================================================================================================
-// v2: same math and register layout as above, different tile pipeline.  K / V^T tiles go global -> LDS by LDS-DMA
-// (no register staging, no commit stores) into a DOUBLE-buffered pair, so a tile costs one s_barrier instead of two and
-// its loads have a whole tile of MFMA + softmax time to land.  Ablation on the v1 kernel (profiles/README.md): removing
-// the per-tile commit + 2 barriers alone was worth 25 % (d=40) to 36 % (d=80).
-//  * K tile: dense rows of d halfs (d/8 16-byte chunks); chunk c of row `row` sits at physical chunk c ^ swz(row), with
-//    the XOR width chosen from the row stride so that 8 consecutive rows land in 8 distinct 16-byte slots of a 128-byte
-//    bank line (d=40: stride 80 B needs none; d=80: 1 bit; d=160: 2 bits).  The DMA writes lane-linear, so the swizzle
-//    is applied to the SOURCE address of each lane and to the fragment read alike.
-//  * V^T tile: 32*DV rows of 64 keys (8 chunks), chunk ^= row & 7.  Rows >= d are sourced from a zero page (and the
-//    spare "ones" row from a page of fp16 1.0) every tile: the tile is always whole instructions, nothing to pre-fill.
-//  * a d that is an odd multiple of 8 leaves one pad chunk in the last QK^T k-step; the matching Q fragment is zero and
-//    the pad chunk reads the next row's first chunk (or the zero-filled slack after the last row): 0 * finite = 0.
-// =====================================================================================================================
 __device__ uint4 g_att_zero[8];                                                     // 128 zero bytes
 __device__ uint4 g_att_ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};   // 8 x fp16 1.0
 
@@ -566,47 +319,36 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
     }
 }
 
+thread_local const char* t_last_attn_kernel = "";
+
 template <int DK>
 void launch_attn(const AttnParams& p, hipStream_t s) {
-    static const int env_kt = getenv("LD_ATTN_KT") ? atoi(getenv("LD_ATTN_KT")) : 64;   // A/B knob; 64 measured best (profiles/r01_c)
     const int nblk = ((p.Lq + 127) / 128) * p.H * p.B;
-    static const int env_smx = getenv("LD_ATTN_SMX") ? atoi(getenv("LD_ATTN_SMX")) : 1;
     // min waves per SIMD handed to __launch_bounds__: with it hipcc keeps the MFMA accumulators in VGPRs (no v_accvgpr
     // copies around the softmax) and fits 3-4 waves per SIMD for the small heads: +25 % at d=40 (profiles/README.md).
-    static const int env_wps = getenv("LD_ATTN_WPS") ? atoi(getenv("LD_ATTN_WPS")) : -1;   // -1 auto, 0 none
     constexpr int AUTO_WPS = DK <= 5 ? 3 : 2;
-    static const bool env_v1 = getenv("LD_ATTN_V1") != nullptr;   // A/B knob: the register-staged single-buffer kernel
-    if (!env_v1) {
-        // 8-wave workgroups (256 queries share a K / V^T tile: half the LDS-DMA and barrier work per query) once there
-        // are enough 256-query blocks to fill the chip at the same waves/SIMD; 4-wave workgroups otherwise.
-        static const int env_nw = getenv("LD_ATTN_NW") ? atoi(getenv("LD_ATTN_NW")) : 0;
-        const bool masked = p.causal || (p.Lk % 64) != 0;
-        const long long nblk8 = (long long)((p.Lq + 255) / 256) * p.H * p.B;
-        // measured (tools/attn_micro.py): d=40 L=4096 -1.6 %, L=16384 -5 %; d=80 L=1024 +1 % (142 VGPRs: one workgroup per CU)
-        const bool big = env_nw ? env_nw == 8 : (DK <= 4 && p.Lq >= 2048 && nblk8 >= 512);
-        if (big) {
-            constexpr int W8 = DK <= 4 ? 4 : 2;   // waves per SIMD the register budget is cut for (two or one workgroup per CU)
-            if (masked) hipLaunchKernelGGL((flash_attn2_kernel<DK, true, 8, W8>), dim3((unsigned)nblk8), dim3(512), 0, s, p);
-            else hipLaunchKernelGGL((flash_attn2_kernel<DK, false, 8, W8>), dim3((unsigned)nblk8), dim3(512), 0, s, p);
-        } else {
-            if (masked) hipLaunchKernelGGL((flash_attn2_kernel<DK, true, 4, AUTO_WPS>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
-            else hipLaunchKernelGGL((flash_attn2_kernel<DK, false, 4, AUTO_WPS>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
-        }
-        return;
+    // 8-wave workgroups (256 queries share a K / V^T tile: half the LDS-DMA and barrier work per query) once there
+    // are enough 256-query blocks to fill the chip at the same waves/SIMD; 4-wave workgroups otherwise.
+    const bool masked = p.causal || (p.Lk % 64) != 0;
+    const long long nblk8 = (long long)((p.Lq + 255) / 256) * p.H * p.B;
+    // measured (tools/attn_micro.py): d=40 L=4096 -1.6 %, L=16384 -5 %; d=80 L=1024 +1 % (142 VGPRs: one workgroup per CU)
+    const bool big = DK <= 4 && p.Lq >= 2048 && nblk8 >= 512;
+    static const std::string names[4] = {"flash_attn2_kernel<" + std::to_string(DK) + ",plain,4>", "flash_attn2_kernel<" + std::to_string(DK) + ",masked,4>",
+                                         "flash_attn2_kernel<" + std::to_string(DK) + ",plain,8>", "flash_attn2_kernel<" + std::to_string(DK) + ",masked,8>"};
+    t_last_attn_kernel = names[(big ? 2 : 0) + (masked ? 1 : 0)].c_str();
+    if (big) {
+        constexpr int W8 = DK <= 4 ? 4 : 2;   // waves per SIMD the register budget is cut for (two or one workgroup per CU)
+        if (masked) hipLaunchKernelGGL((flash_attn2_kernel<DK, true, 8, W8>), dim3((unsigned)nblk8), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((flash_attn2_kernel<DK, false, 8, W8>), dim3((unsigned)nblk8), dim3(512), 0, s, p);
+    } else {
+        if (masked) hipLaunchKernelGGL((flash_attn2_kernel<DK, true, 4, AUTO_WPS>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((flash_attn2_kernel<DK, false, 4, AUTO_WPS>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
     }
-    if (env_wps != 0 && !(DK <= 5 && env_kt == 128) && env_smx != 0) {
-        hipLaunchKernelGGL((flash_attn_kernel<DK, 64, 1, AUTO_WPS>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
-        return;
-    }
-    if (DK <= 5 && env_kt == 128)
-        hipLaunchKernelGGL((flash_attn_kernel<DK, (DK <= 5 ? 128 : 64)>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
-    else if (env_smx == 0)
-        hipLaunchKernelGGL((flash_attn_kernel<DK, 64, 0>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
-    else
-        hipLaunchKernelGGL((flash_attn_kernel<DK, 64, 1>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
 }
 
 }  // namespace
+
+const char* attention_last_kernel_name() { return t_last_attn_kernel; }
 
 int attention_launch(const AttnParams& p, hipStream_t stream) {
     if (p.Q == nullptr || p.K == nullptr || p.Vt == nullptr || p.O == nullptr) return LD_ERR_ARG;

@@ -57,6 +57,7 @@ struct GemmParams {
 };
 
 bool gemm_ln_fold_available();   // the kernels that implement stat_out / ln_stat are the ones gemm_launch will pick
+const char* gemm_last_kernel_name();   // kernel instantiation the calling thread's last gemm_launch dispatched
 
 // BN the GEGLU weight interleave must use for a projection with N (=2*inner) output rows
 static inline int gemm_pick_bn(int N) { return (N % 160 == 0) ? 160 : 128; }

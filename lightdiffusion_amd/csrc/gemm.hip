@@ -1,15 +1,17 @@
 // MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950.
 //
 // Tile: BM x BN x 64, 4 waves (2x2), each wave (BM/2)x(BN/2) as 16x16x32 f16 MFMA tiles.
-// Staging: global -> registers (issued before the MFMA phase of the current tile, T14 split) -> LDS, two LDS
-// stages, ONE barrier per K-step.  LDS tiles are [rows][64 halfs] with the 16-byte chunk index XOR-swizzled
-// by (row & 7): ds_read_b128 fragment reads are bank-conflict free (cdna guide T2).
+// Staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of slabs, ONE barrier per 64-wide K slab.
+// LDS tiles are [rows][64 halfs] with the 16-byte chunk index XOR-swizzled by (row & 7) on the DMA source address
+// and on the fragment read: ds_read_b128 fragment reads are bank-conflict free (cdna guide T2, rule 21).
 // MFMA operands are swapped (a := W fragment, b := A fragment) so that each lane ends up with 4 consecutive
 // output channels of one output row -> 8-byte LDS writes / 16-byte split-K stores in the epilogue.
 // Epilogue: accumulators -> fp16 tile in LDS -> row-wise 16-byte coalesced stores with the fused bias /
 // time-embedding broadcast / SiLU / GEGLU / residual.
 #include <cstdlib>
-
+#include <mutex>
+#include <set>
+#include <string>
 #include <type_traits>
 
 #include "gemm.h"
@@ -224,515 +226,8 @@ __device__ __forceinline__ void ln_apply(const GemmParams& p, f32x4 (&acc)[TM][T
     }
 }
 
-template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmParams p) {
-    constexpr int WTM = BM / 2, WTN = BN / 2;   // wave tile
-    constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_IT = (BM * 8) / NT;         // 16-byte chunks per thread per A tile
-    constexpr int B_IT = (BN * 8 + NT - 1) / NT;
-    constexpr int STAGE = (BM + BN) * BK;       // halfs per stage
-    constexpr int CLD = BN + 8;                 // epilogue tile row stride (halfs)
-    static_assert(BM * CLD <= 2 * STAGE, "epilogue tile must fit in the staging LDS");
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
-    const int z = blockIdx.z;
-
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int tiles = tiles_m * tiles_n;
-    const int splitk = p.splitk > 1 ? p.splitk : 1;
-    int bid = xcd_remap(blockIdx.x, tiles * splitk);
-    const int ks = bid / tiles;
-    bid -= ks * tiles;
-    // n fastest: consecutive blocks (one XCD) sweep the N tiles of one M panel -> A panel stays in that L2;
-    // m fastest: they sweep the M tiles of one weight panel (chosen on the host by streamed bytes)
-    const int tn_i = p.m_fastest ? bid / tiles_m : bid % tiles_n;
-    const int tm_i = p.m_fastest ? bid % tiles_m : bid / tiles_n;
-    const int m0 = tm_i * BM, n0 = tn_i * BN;
-
-    const int KT = (p.K + BK - 1) / BK;
-    const int kt_begin = (int)((long long)ks * KT / splitk), kt_end = (int)((long long)(ks + 1) * KT / splitk);
-
-    const half_t* Ab = p.A + (long long)z * p.sA;
-    const half_t* A2b = p.A2;
-    const half_t* Wb = p.W + (long long)z * p.sW;
-    const int Cin = p.C1 + p.C2;
-
-    // ---- per-thread staging coordinates (fixed over the K loop)
-    int a_row[A_IT];
-    bool a_ok[A_IT];
-    long long a_base[A_IT];   // plain: element offset of the row;  conv: image index
-    int a_iy0[A_IT], a_ix0[A_IT];
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int q = tid + i * NT;
-        const int row = q >> 3;
-        a_row[i] = row;
-        const int m = m0 + row;
-        a_ok[i] = m < p.M;
-        if (CONV) {
-            const int hw = p.Ho * p.Wo;
-            const int mm = a_ok[i] ? m : 0;
-            const int img = mm / hw, rem = mm - img * hw;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            a_base[i] = img;
-            a_iy0[i] = oy * p.stride - p.pad;
-            a_ix0[i] = ox * p.stride - p.pad;
-        } else {
-            a_base[i] = (long long)m * p.lda;
-            a_iy0[i] = a_ix0[i] = 0;
-        }
-    }
-    const int ch = tid & 7;   // chunk within the 64-wide K slab (same for every i: NT % 8 == 0)
-
-    uint4 ra[A_IT], rb[B_IT];
-
-    auto load_tiles = [&](int kt) {
-        const int k0 = kt * BK;
-        if (CONV) {
-            const int tap = k0 / Cin;
-            const int c0 = k0 - tap * Cin;
-            const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
-            const bool second = c0 >= p.C1;
-            const half_t* src = second ? A2b : Ab;
-            const int Cs = second ? p.C2 : p.C1;
-            const int cl = (second ? c0 - p.C1 : c0) + ch * 8;
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv;
-                int sy = iy, sx = ix;
-                if (p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws) {   // exact 2x nearest upsample
-                    sy = iy >> 1;
-                    sx = ix >> 1;
-                } else if (p.Hv != p.Hs || p.Wv != p.Ws) {    // general nearest resize: src = floor(dst * in / out)
-                    sy = (int)((long long)iy * p.Hs / p.Hv);
-                    sx = (int)((long long)ix * p.Ws / p.Wv);
-                }
-                const long long off = ((a_base[i] * p.Hs + sy) * p.Ws + sx) * Cs + cl;
-                ra[i] = ok ? ld16(src + off) : zero16();
-            }
-        } else {
-            const int kc = k0 + ch * 8;
-            const bool kok = kc < p.K;
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) ra[i] = (a_ok[i] && kok) ? ld16(Ab + a_base[i] + kc) : zero16();
-        }
-        const int kc = k0 + ch * 8;
-        const bool kok = kc < p.K;
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int q = tid + i * NT;
-            const int row = q >> 3;
-            const bool ok = (q < BN * 8) && (n0 + row < p.n_valid) && kok;
-            rb[i] = ok ? ld16(Wb + (long long)(n0 + row) * p.ldw + kc) : zero16();
-        }
-    };
-
-    auto store_tiles = [&](int stage) {
-        half_t* As = smem + stage * STAGE;
-        half_t* Bs = As + BM * BK;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) st16(As + a_row[i] * BK + ((ch ^ (a_row[i] & 7)) << 3), ra[i]);
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int q = tid + i * NT;
-            const int row = q >> 3;
-            if (q < BN * 8) st16(Bs + row * BK + ((ch ^ (row & 7)) << 3), rb[i]);
-        }
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int fr = lane & 15, fq = lane >> 4;
-
-    if (kt_begin < kt_end) {
-        load_tiles(kt_begin);
-        store_tiles(0);
-    }
-    __syncthreads();
-
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int stage = (kt - kt_begin) & 1;
-        const bool more = kt + 1 < kt_end;
-        if (more) load_tiles(kt + 1);   // global loads in flight under the MFMA phase below
-        const half_t* As = smem + stage * STAGE;
-        const half_t* Bs = As + BM * BK;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8 bf[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = wn0 + j * 16 + fr;
-                bf[j] = as_half8(ld16(Bs + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3)));
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm0 + i * 16 + fr;
-                const half8 af = as_half8(ld16(As + row * BK + (((kk * 4 + fq) ^ (row & 7)) << 3)));
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af, acc[i][j], 0, 0, 0);
-            }
-        }
-        if (more) store_tiles(stage ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue.  D = Wfrag x Afrag^T: lane holds rows n = fq*4 + r (r = 0..3) of column m = fr.
-    if (splitk > 1) {
-        float* part = p.partial + (long long)ks * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm0 + i * 16 + fr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn0 + j * 16 + fq * 4;
-                if (m < p.M && n < p.N) {
-                    f32x4 v = acc[i][j];
-                    v *= p.alpha;
-                    *reinterpret_cast<f32x4*>(part + (long long)m * p.N + n) = v;
-                }
-            }
-        }
-        return;
-    }
-
-    half_t* Cs = smem;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int ml = wm0 + i * 16 + fr;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nl = wn0 + j * 16 + fq * 4;
-            half4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] * p.alpha);
-            *reinterpret_cast<half4*>(Cs + ml * CLD + nl) = h;
-        }
-    }
-    __syncthreads();
-
-    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid);
-}
-
-// =====================================================================================================================
-// v2 main loop: direct global->LDS loads (global_load_lds_dwordx4) into a 4-stage ring, 3 K-slabs (BK = 32) in flight
-// behind a COUNTED vmcnt and ONE raw s_barrier per K-step; no staging registers, no ds_write, address generation hoisted
-// out of the loop (pointers advance by a constant; conv tap / concat-source changes are a rare wave-uniform branch).
-// LDS rows are 64 B (4 chunks of 16 B); the DMA writes lane-linear, so the bank swizzle is applied to the SOURCE chunk
-// and to the fragment read alike (guide rule 21): physical chunk = logical chunk ^ SWZ[(row >> 2) & 3], SWZ = {0,2,3,1},
-// which makes every ds_read_b128 lane group of the 16x16x32 fragment reads hit 16 distinct 16-byte slots.
-// =====================================================================================================================
-__device__ uint4 g_zero_page[8];   // 128 zero bytes: the source of padded / out-of-range chunks
-__device__ uint4 g_zero_row[4096];  // 64 KB of zeros: a whole K-row of padding that the v3 loader can step through
-
-__device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
-
-template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(NT, 2) void gemm2_kernel(const GemmParams p) {
-    constexpr int BK2 = 32, NST = 4, PF = 3;
-    constexpr int WTM = BM / 2, WTN = BN / 2;
-    constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_CH = BM * 4, B_CH = BN * 4;                 // 16-byte chunks per stage
-    constexpr int A_IT = A_CH / NT;                             // 2 (BM=128) or 1 (BM=64)
-    constexpr int B_FULL = B_CH / NT;                           // B instructions every wave issues
-    constexpr bool B_TAIL = (B_CH % NT) != 0;                   // + one more for waves 0,1 (BN = 160)
-    constexpr int STAGE = (BM + BN) * BK2;                      // halfs per stage
-    constexpr int CLD = BN + 8;
-    static_assert(BM * CLD <= NST * STAGE, "epilogue tile must fit in the ring");
-    static_assert(!B_TAIL || (B_CH % NT) == NT / 2, "tail = exactly waves 0 and 1");
-    __shared__ __attribute__((aligned(16))) half_t smem[NST * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
-    const int z = blockIdx.z;
-
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int tiles = tiles_m * tiles_n;
-    const int splitk = p.splitk > 1 ? p.splitk : 1;
-    int bid = xcd_remap(blockIdx.x, tiles * splitk);
-    const int ks = bid / tiles;
-    bid -= ks * tiles;
-    const int tn_i = p.m_fastest ? bid / tiles_m : bid % tiles_n;
-    const int tm_i = p.m_fastest ? bid % tiles_m : bid / tiles_n;
-    const int m0 = tm_i * BM, n0 = tn_i * BN;
-
-    const int KT = (p.K + BK2 - 1) / BK2;
-    const int kt_begin = (int)((long long)ks * KT / splitk), kt_end = (int)((long long)(ks + 1) * KT / splitk);
-
-    const half_t* Ab = p.A + (long long)z * p.sA;
-    const half_t* Wb = p.W + (long long)z * p.sW;
-    const half_t* zp = reinterpret_cast<const half_t*>(g_zero_page);
-    const int Cin = p.C1 + p.C2;
-
-    // ---- loader state.  Thread owns physical chunk q = tid + i*NT of the A tile: row = q >> 2, slot = q & 3, and
-    // fetches the LOGICAL chunk lc = slot ^ swz(row) of that row from global memory.
-    int a_lc[A_IT];
-    bool a_ok[A_IT];
-    int a_img[A_IT], a_iy0[A_IT], a_ix0[A_IT];
-    const half_t* a_ptr[A_IT];      // current source of this thread's chunk (valid or not)
-    bool a_val[A_IT];
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int q = tid + i * NT;
-        const int row = q >> 2;
-        a_lc[i] = (q & 3) ^ swz4(row);
-        const int m = m0 + row;
-        a_ok[i] = m < p.M;
-        a_img[i] = a_iy0[i] = a_ix0[i] = 0;
-        a_ptr[i] = zp;
-        a_val[i] = false;
-        if (CONV) {
-            const int hw = p.Ho * p.Wo;
-            const int mm = a_ok[i] ? m : 0;
-            const int img = mm / hw, rem = mm - img * hw;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            a_img[i] = img;
-            a_iy0[i] = oy * p.stride - p.pad;
-            a_ix0[i] = ox * p.stride - p.pad;
-        } else {
-            a_ptr[i] = Ab + (long long)(a_ok[i] ? m : 0) * p.lda + a_lc[i] * 8;
-        }
-    }
-    // conv: (re)compute the pointers for the K position k0 (start of a tap/source segment or of the split)
-    int seg_left = 0;   // K-steps until the next segment boundary (conv only)
-    int a_step[A_IT];   // per-slab pointer stride with validity folded in (0 = parked on the zero page)
-    auto conv_seek = [&](int k0) {
-        const int tap = k0 / Cin;
-        const int c0 = k0 - tap * Cin;
-        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
-        const bool second = c0 >= p.C1;
-        const half_t* src = second ? p.A2 : Ab;
-        const int Cs = second ? p.C2 : p.C1;
-        const int cl = second ? c0 - p.C1 : c0;
-        seg_left = ((second ? Cin : p.C1) - c0) / BK2;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv && tap < p.ksize * p.ksize;
-            int sy = iy, sx = ix;
-            if (p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws) {
-                sy = iy >> 1;
-                sx = ix >> 1;
-            } else if (p.Hv != p.Hs || p.Wv != p.Ws) {
-                sy = (int)((long long)iy * p.Hs / p.Hv);
-                sx = (int)((long long)ix * p.Ws / p.Wv);
-            }
-            a_val[i] = ok;
-            a_ptr[i] = ok ? src + (((long long)a_img[i] * p.Hs + sy) * p.Ws + sx) * Cs + cl + a_lc[i] * 8 : zp;
-            a_step[i] = ok ? BK2 : 0;
-        }
-    };
-
-    // B (weights): chunk q -> row = q >> 2
-    constexpr int B_IT = B_FULL + (B_TAIL ? 1 : 0);
-    const half_t* b_ptr[B_IT];
-    bool b_ok[B_IT];
-    int b_lc[B_IT];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-        const int q = tid + i * NT;
-        const int row = q >> 2;
-        b_lc[i] = (q & 3) ^ swz4(row);
-        b_ok[i] = (q < B_CH) && (n0 + row < p.n_valid);
-        b_ptr[i] = Wb + (long long)(b_ok[i] ? n0 + row : 0) * p.ldw + b_lc[i] * 8;
-    }
-    const bool tail_wave = B_TAIL && wid < 2;
-
-    // K tail (K % 32 != 0, plain mode only) needs a per-chunk bound check; SD1.5 shapes never do.
-    const bool ktail = !CONV && (p.K % BK2) != 0;
-    // per-slab pointer strides with the row validity folded in: invalid rows sit on the zero page and do not move
-    int b_step[B_IT];
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        if (!CONV) {
-            if (!a_ok[i]) a_ptr[i] = zp;
-            a_step[i] = a_ok[i] ? BK2 : 0;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-        if (!b_ok[i]) b_ptr[i] = zp;
-        b_step[i] = b_ok[i] ? BK2 : 0;
-    }
-
-    // issue the loads of K-slab kt into ring stage `st` (every wave issues the same number of instructions per slab)
-    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    auto issue = [&](int kt, int st) {
-        const unsigned As = smem_base + (unsigned)(st * STAGE) * 2u;     // byte addresses in LDS, wave-uniform
-        const unsigned Bs = As + (unsigned)(BM * BK2) * 2u;
-        const int k0 = kt * BK2;
-        if (kt >= kt_end) {
-            // look-ahead past the split's last slab: same number of DMAs (keeps the vmcnt arithmetic uniform), all from
-            // the zero page; wave-uniform branch, no per-lane selects in the steady state below
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) glds16(zp, As + (unsigned)(i * NT + wid * 64) * 16u);
-#pragma unroll
-            for (int i = 0; i < B_FULL; ++i) glds16(zp, Bs + (unsigned)(i * NT + wid * 64) * 16u);
-            if (B_TAIL && tail_wave) glds16(zp, Bs + (unsigned)(B_FULL * NT + wid * 64) * 16u);
-            return;
-        }
-        if (ktail) {
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) glds16((k0 + a_lc[i] * 8 < p.K) ? a_ptr[i] : zp, As + (unsigned)(i * NT + wid * 64) * 16u);
-#pragma unroll
-            for (int i = 0; i < B_FULL; ++i) glds16((k0 + b_lc[i] * 8 < p.K) ? b_ptr[i] : zp, Bs + (unsigned)(i * NT + wid * 64) * 16u);
-            if (B_TAIL && tail_wave)
-                glds16((k0 + b_lc[B_IT - 1] * 8 < p.K) ? b_ptr[B_IT - 1] : zp, Bs + (unsigned)(B_FULL * NT + wid * 64) * 16u);
-        } else {
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) glds16(a_ptr[i], As + (unsigned)(i * NT + wid * 64) * 16u);
-#pragma unroll
-            for (int i = 0; i < B_FULL; ++i) glds16(b_ptr[i], Bs + (unsigned)(i * NT + wid * 64) * 16u);
-            if (B_TAIL && tail_wave) glds16(b_ptr[B_IT - 1], Bs + (unsigned)(B_FULL * NT + wid * 64) * 16u);
-        }
-        // advance to the next K-slab
-        if (CONV) {
-            if (--seg_left <= 0) {
-                conv_seek(k0 + BK2);
-            } else {
-#pragma unroll
-                for (int i = 0; i < A_IT; ++i) a_ptr[i] += a_step[i];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) a_ptr[i] += a_step[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) b_ptr[i] += b_step[i];
-    };
-
-    // position the loaders at the split's first slab
-    if (CONV) {
-        conv_seek(kt_begin * BK2);
-    } else {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) a_ptr[i] += (long long)kt_begin * a_step[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) b_ptr[i] += (long long)kt_begin * b_step[i];
-
-    // ---- fragment read offsets (halfs, within a stage)
-    const int fr = lane & 15, fq = lane >> 4;
-    int a_off[TM], b_off[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = wm0 + i * 16 + fr;
-        a_off[i] = row * BK2 + ((fq ^ swz4(row)) << 3);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int row = wn0 + j * 16 + fr;
-        b_off[j] = BM * BK2 + row * BK2 + ((fq ^ swz4(row)) << 3);
-    }
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // ---- prologue: PF slabs in flight
-#pragma unroll
-    for (int t = 0; t < PF; ++t) issue(kt_begin + t, t);
-
-    constexpr int LPT_HI = A_IT + B_IT;          // loads per slab, waves 0-1
-    constexpr int LPT_LO = A_IT + B_FULL;        // waves 2-3
-    // Register double-buffered fragments: the ds_reads of slab t+1 are issued BEFORE the MFMAs of slab t, so their
-    // latency hides under 20 (16) MFMAs instead of stalling every slab.  Per step:
-    //   [slab t+1 landed: counted vmcnt] [barrier] [refill the stage slab t used] [read frags(t+1)] [MFMA frags(t)]
-    //   [lgkmcnt(0): frags(t+1) are in registers, so the NEXT barrier also proves nobody still reads slab t+1's stage... ]
-    half8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    auto wait_landed = [&]() {
-        if (B_TAIL && tail_wave) wait_vmcnt<LPT_HI * (PF - 1)>();
-        else wait_vmcnt<LPT_LO * (PF - 1)>();
-    };
-    auto read_frags = [&](int stg, half8 (&fa)[TM], half8 (&fb)[TN]) {
-        const half_t* S = smem + stg * STAGE;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = as_half8(ld16(S + b_off[j]));
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = as_half8(ld16(S + a_off[i]));
-    };
-    auto mma = [&](const half8 (&fa)[TM], const half8 (&fb)[TN]) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    };
-    // one pipeline step: consume `cur` (slab kt, already in registers), fetch slab kt+1 into `nxt`
-    auto step = [&](int kt, int st, const half8 (&cfa)[TM], const half8 (&cfb)[TN], half8 (&nfa)[TM], half8 (&nfb)[TN]) {
-        wait_landed();                               // slab kt+1 landed (this wave's share)
-        __builtin_amdgcn_s_barrier();                // ... everyone's share; and all reads of slab kt's stage have completed
-        issue(kt + PF + 1, st);                      // refill the stage slab kt occupied
-        read_frags((st + 1) & (NST - 1), nfa, nfb);  // slab kt+1 -> registers (latency hidden by the MFMAs below)
-        __builtin_amdgcn_sched_barrier(0);           // keep the reads AHEAD of the MFMAs (hipcc otherwise sinks them below
-        mma(cfa, cfb);                               //  the MFMAs and reuses the fragment registers: latency exposed)
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-
-    int st = 0;
-    {   // slab kt_begin -> registers
-        if (B_TAIL && tail_wave) wait_vmcnt<LPT_HI * (PF - 1)>();
-        else wait_vmcnt<LPT_LO * (PF - 1)>();
-        __builtin_amdgcn_s_barrier();
-        issue(kt_begin + PF, PF);                    // 4th stage: now PF+... slabs are in flight again
-        read_frags(0, fa0, fb0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    int kt = kt_begin;
-    for (; kt + 1 < kt_end; kt += 2) {
-        step(kt, st, fa0, fb0, fa1, fb1);
-        st = (st + 1) & (NST - 1);
-        step(kt + 1, st, fa1, fb1, fa0, fb0);
-        st = (st + 1) & (NST - 1);
-    }
-    if (kt < kt_end) mma(fa0, fb0);                  // odd slab count: the last slab is already in registers
-    wait_vmcnt<0>();                             // drain the look-ahead (zero-page) loads before the ring is reused
-    __builtin_amdgcn_s_barrier();
-
-    // ---- epilogue (identical to v1)
-    if (splitk > 1) {
-        float* part = p.partial + (long long)ks * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm0 + i * 16 + fr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn0 + j * 16 + fq * 4;
-                if (m < p.M && n < p.N) {
-                    f32x4 v = acc[i][j];
-                    v *= p.alpha;
-                    *reinterpret_cast<f32x4*>(part + (long long)m * p.N + n) = v;
-                }
-            }
-        }
-        return;
-    }
-    half_t* Cs = smem;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int ml = wm0 + i * 16 + fr;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nl = wn0 + j * 16 + fq * 4;
-            half4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] * p.alpha);
-            *reinterpret_cast<half4*>(Cs + ml * CLD + nl) = h;
-        }
-    }
-    __syncthreads();
-    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid);
-}
+__device__ uint4 g_zero_row[4096];  // 64 KB of zeros: conv taps outside the image read it, stepped through like real data (one
+                                    // tap's channel run at a time, so it only has to cover max(C1, C2) <= 32768 halfs)
 
 // =====================================================================================================================
 // v3: 64-wide K slabs, a TWO-stage LDS-DMA ring (2 x (BM+BN) x 128 B <= 73.7 KB) and two workgroups per CU.
@@ -1328,94 +823,62 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     }
 }
 
-int v4_max_blocks() {   // plain GEMMs with at most this many workgroups take the producer/consumer kernel (measured at B=1: 256 -> 169.3,
-    // 512 -> 167.8, 768 -> 166.2, 1280 -> 164.8 steps/s); LD_GEMM_V4_MAX overrides (A/B knob)
-    static const int v = getenv("LD_GEMM_V4_MAX") ? atoi(getenv("LD_GEMM_V4_MAX")) : 256;
-    return v;
-}
-bool use_v1() {
-    static const bool v = getenv("LD_GEMM_V1") != nullptr;
-    return v;
-}
-int v3_min_k() {   // K from which the 64-wide-slab kernel (v3) is used instead of v2; LD_GEMM_V3_MINK overrides, 0 = never.
-    // measured (profiles/r01_c): v3 with a 2-stage ring wins or ties v2 on every shape of the UNet, so the default is "always"
-    static const int v = getenv("LD_GEMM_V3_MINK") ? atoi(getenv("LD_GEMM_V3_MINK")) : 1;
-    return v;
-}
+// plain GEMMs with at most this many workgroups take the producer/consumer kernel (measured at B=1: 256 -> 169.3, 512 -> 167.8,
+// 768 -> 166.2, 1280 -> 164.8 steps/s)
+constexpr int V4_MAX_BLOCKS = 256;
 
-template <int BM, int BN>
-void launch_cfg_v34(const GemmParams& p, hipStream_t s) {   // tile shapes that only the v3 / v4 kernels are instantiated for
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    const int sk = p.splitk > 1 ? p.splitk : 1;
-    dim3 grid(tiles * sk, 1, p.batch);
-    static const int env_v4 = getenv("LD_GEMM_V4") ? atoi(getenv("LD_GEMM_V4")) : -1;
-    if (env_v4 == 1 || (env_v4 < 0 && !p.conv && (long long)tiles * sk * p.batch <= v4_max_blocks())) {
-        if (p.conv) hipLaunchKernelGGL((gemm4_kernel<BM, BN, true>), grid, dim3(2 * NT), 0, s, p);
-        else hipLaunchKernelGGL((gemm4_kernel<BM, BN, false>), grid, dim3(2 * NT), 0, s, p);
-    } else {
-        if (p.conv) hipLaunchKernelGGL((gemm3_kernel<BM, BN, true, 2>), grid, dim3(NT), 0, s, p);
-        else hipLaunchKernelGGL((gemm3_kernel<BM, BN, false, 2>), grid, dim3(NT), 0, s, p);
-    }
+// name of the kernel instantiation the last gemm_launch on this thread dispatched (ld_unet_profile groups by it)
+thread_local const char* t_last_kernel = "";
+const char* intern_name(const std::string& s) {   // stable storage for composed names (a handful per process)
+    static std::mutex mu;
+    static std::set<std::string> pool;
+    std::lock_guard<std::mutex> lock(mu);
+    return pool.insert(s).first->c_str();
 }
 
 template <int BM, int BN>
 void launch_cfg(const GemmParams& p, hipStream_t s) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int sk = p.splitk > 1 ? p.splitk : 1;
-    dim3 grid(tiles * sk, 1, p.batch), block(NT);
-    if (use_v1()) {
-        if (p.conv)
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, block, 0, s, p);
-        else
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, block, 0, s, p);
-    } else if (v3_min_k() > 0 && p.K / sk >= v3_min_k() && p.K <= 32000) {   // K row of zeros (g_zero_row) must cover K
-        // producer/consumer kernel: wins where a plain GEMM leaves at most one workgroup per CU (batch-1 step: +5.6 % whole
-        // step, same box A/B); loses on convs and wherever two v3 workgroups share a CU.  LD_GEMM_V4 = 0 never, 1 always.
-        static const int env_v4 = getenv("LD_GEMM_V4") ? atoi(getenv("LD_GEMM_V4")) : -1;
-        if (env_v4 == 1 || (env_v4 < 0 && !p.conv && (long long)tiles * sk * p.batch <= v4_max_blocks())) {
-            dim3 block8(2 * NT);
-            if (p.conv)
-                hipLaunchKernelGGL((gemm4_kernel<BM, BN, true>), grid, block8, 0, s, p);
-            else
-                hipLaunchKernelGGL((gemm4_kernel<BM, BN, false>), grid, block8, 0, s, p);
-            return;
-        }
-        static const int env_nst = getenv("LD_GEMM_V3_NST") ? atoi(getenv("LD_GEMM_V3_NST")) : 0;   // A/B knob
-        const bool deep = env_nst == 4;   // measured (tools/gemm_micro.py small): no gain for lone workgroups, so never automatic
-        if (deep) {
-            if (p.conv)
-                hipLaunchKernelGGL((gemm3_kernel<BM, BN, true, 4>), grid, block, 0, s, p);
-            else
-                hipLaunchKernelGGL((gemm3_kernel<BM, BN, false, 4>), grid, block, 0, s, p);
-        } else {
-            if (p.conv)
-                hipLaunchKernelGGL((gemm3_kernel<BM, BN, true, 2>), grid, block, 0, s, p);
-            else
-                hipLaunchKernelGGL((gemm3_kernel<BM, BN, false, 2>), grid, block, 0, s, p);
-        }
+    dim3 grid(tiles * sk, 1, p.batch);
+    // producer/consumer kernel: wins where a plain GEMM leaves at most one workgroup per CU (batch-1 step: +5.6 % whole step,
+    // same box A/B); loses on convs and wherever two v3 workgroups share a CU.
+    if (!p.conv && (long long)tiles * sk * p.batch <= V4_MAX_BLOCKS) {
+        static const std::string name = "gemm4_kernel<" + std::to_string(BM) + "," + std::to_string(BN) + ",plain>";
+        t_last_kernel = name.c_str();
+        hipLaunchKernelGGL((gemm4_kernel<BM, BN, false>), grid, dim3(2 * NT), 0, s, p);
+    } else if (p.conv) {
+        static const std::string name = "gemm3_kernel<" + std::to_string(BM) + "," + std::to_string(BN) + ",conv>";
+        t_last_kernel = name.c_str();
+        hipLaunchKernelGGL((gemm3_kernel<BM, BN, true, 2>), grid, dim3(NT), 0, s, p);
     } else {
-        if (p.conv)
-            hipLaunchKernelGGL((gemm2_kernel<BM, BN, true>), grid, block, 0, s, p);
-        else
-            hipLaunchKernelGGL((gemm2_kernel<BM, BN, false>), grid, block, 0, s, p);
+        static const std::string name = "gemm3_kernel<" + std::to_string(BM) + "," + std::to_string(BN) + ",plain>";
+        t_last_kernel = name.c_str();
+        hipLaunchKernelGGL((gemm3_kernel<BM, BN, false, 2>), grid, dim3(NT), 0, s, p);
     }
 }
 
 }  // namespace
 
-// tuning hook (tools/gemm_sweep.py): force tile height / split-K for every following launch; 0 = automatic
+#ifdef LD_AB_BUILD
+// tuning hook of the A/B build (tools/gemm_sweep.py): force tile height / split-K for every following launch; 0 = automatic.
+// Not part of the shipped library: `make AB=1` builds libld_mi355x_ab.so with it.
 static int g_force_bm = 0, g_force_sk = 0;
 extern "C" void ld_debug_gemm_override(int bm, int splitk) {
     g_force_bm = bm;
     g_force_sk = splitk;
 }
+#endif
 
-bool gemm_ln_fold_available() { return !use_v1() && v3_min_k() == 1; }
+bool gemm_ln_fold_available() { return true; }
+const char* gemm_last_kernel_name() { return t_last_kernel; }
 
 int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     GemmParams p = pin;
+#ifdef LD_AB_BUILD
     if (g_force_bm) p.bm = g_force_bm;
     if (g_force_sk) p.splitk = g_force_sk;
+#endif
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.A == nullptr || p.W == nullptr || p.C == nullptr) return LD_ERR_ARG;
     if ((p.N & 7) || (p.K & 7) || (p.ldw & 7) || (p.ldc & 7)) return LD_ERR_SHAPE;
     if (p.conv) {
@@ -1423,6 +886,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         if (p.ksize != 1 && p.ksize != 3) return LD_ERR_ARG;
         if (p.pad < 0) p.pad = p.ksize >> 1;
         if (Cin <= 0 || (p.C1 % 64) || (p.C2 % 64) || p.K != p.ksize * p.ksize * Cin) return LD_ERR_SHAPE;
+        if (p.C1 > 32768 || p.C2 > 32768) return LD_ERR_SHAPE;   // the stepped zero row (g_zero_row) covers one tap's channel run
         if (p.C2 > 0 && p.A2 == nullptr) return LD_ERR_ARG;
         if (p.M % (p.Ho * p.Wo)) return LD_ERR_SHAPE;
         if (p.batch != 1) return LD_ERR_ARG;
@@ -1433,18 +897,14 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (p.R != nullptr && (p.ldr & 7)) return LD_ERR_SHAPE;
 
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
-    static const int env_bm = getenv("LD_GEMM_BM") ? atoi(getenv("LD_GEMM_BM")) : 0;   // experiments only
-    static const int env_bn = getenv("LD_GEMM_BN") ? atoi(getenv("LD_GEMM_BN")) : 0;
-    if (env_bm && p.bm == 0) p.bm = env_bm;
-    if (env_bn && p.bn == 0 && p.act != 2) p.bn = env_bn;
     int bn = p.bn ? p.bn : gemm_pick_bn(p.N);
     // Skinny plain GEMMs (the batch-1 step's M = 128..2048 projections): with <= 128 tiles of 64 x 160 most CUs idle while
     // each busy one streams 28.7 KB per slab through its one LDS-DMA path; 64 x 64 tiles spread the same work over 2.5x more CUs
     // at 16 KB per slab: 512x1280x1280 12.8 -> 8.0 us, 128x1280x1280 12.4 -> 7.6 us; batch-1 step +6 % (same box), batch 8 neutral.
-    // v3 / v4 kernels only.  Measured no better: the same for convs (their split-K already fills the chip: 156.5 vs 163.0
-    // steps/s), 32-row tiles below it (166.2 vs 165.8).
-    static const int skinny_max = getenv("LD_GEMM_SKINNY") ? atoi(getenv("LD_GEMM_SKINNY")) : 256;   // A/B knob: tile-count threshold, 0 = never
-    const bool skinny_ok = !p.conv && p.act != 2 && p.bn == 0 && p.bm == 0 && (p.N % 64) == 0 && !use_v1() && v3_min_k() > 0 && p.K <= 32000;
+    // Measured no better: the same for convs (their split-K already fills the chip: 156.5 vs 163.0 steps/s), 32-row tiles
+    // below it (166.2 vs 165.8); thresholds 128 / 256 / 512: 162.0 / 163.6 / 164.2 at B=1, 49.25 / 49.38 / 48.48 at B=8.
+    constexpr int skinny_max = 256;
+    const bool skinny_ok = !p.conv && p.act != 2 && p.bn == 0 && p.bm == 0 && (p.N % 64) == 0;
     if (skinny_ok) {
         const long long t160 = (long long)((p.M + 63) / 64) * ((p.N + bn - 1) / bn) * p.batch;
         if (t160 <= skinny_max) bn = 64;
@@ -1461,10 +921,8 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     const bool can_split = p.batch == 1 && p.partial != nullptr;
     const int sk_cap = p.K / 768 < 1 ? 1 : (p.K / 768 > 16 ? 16 : p.K / 768);
     int bm = p.bm, sk = p.splitk;
-    static const bool old_heur = getenv("LD_GEMM_HEUR_OLD") != nullptr;   // A/B knob: the pre-sweep rule
     if (bm == 0) {
-        if (old_heur) bm = tiles128 >= 256 ? 128 : 64;
-        else if (tiles128 >= 512) bm = 128;
+        if (tiles128 >= 512) bm = 128;
         else if (p.K >= 4096 && tiles128 >= 32 && can_split) bm = 128;
         else bm = 64;
     }
@@ -1473,14 +931,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     const int tiles = ((p.M + bm - 1) / bm) * tiles_n;
     if (sk == 0) {
         sk = 1;
-        if (old_heur) {
-            if (can_split && tiles < 384 && KT >= 8) {
-                sk = (512 + tiles - 1) / tiles;
-                if (sk > KT / 4) sk = KT / 4;
-                if (sk > 32) sk = 32;
-                if (sk < 1) sk = 1;
-            }
-        } else if (can_split && tiles * p.batch < 512) {
+        if (can_split && tiles * p.batch < 512) {
             sk = (512 + tiles - 1) / tiles;
             if (sk > sk_cap) sk = sk_cap;
         }
@@ -1491,19 +942,17 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         if (sk > KT) sk = KT;
     }
     if (p.stat_out != nullptr || p.ln_stat != nullptr) {   // LN fold: v3 / v4 kernels, whole K in one workgroup
-        if (!gemm_ln_fold_available() || p.K > 32000 || (p.act == 2 && p.stat_out != nullptr)) return LD_ERR_ARG;
+        if (p.act == 2 && p.stat_out != nullptr) return LD_ERR_ARG;
         sk = 1;
         if (p.stat_parts_out != nullptr) *p.stat_parts_out = tiles_n;
     }
     p.splitk = sk;
     p.bn = bn;
-    static const char* order_env = getenv("LD_GEMM_ORDER");      // debugging / A-B: "n", "m" or unset (auto)
-    if (order_env != nullptr && (order_env[0] == 'n' || order_env[0] == 'm')) p.m_fastest = order_env[0] == 'm';
     // measured (profiles/r01_b): n-fastest wins on every SD1.5 shape — the 9 taps of a 3x3 conv and the N tiles of one
     // M panel re-read the same activations through the XCD's L2, which matters more than re-streaming the weights
     if (p.m_fastest < 0) p.m_fastest = 0;
 
-    if (bn == 64) launch_cfg_v34<64, 64>(p, stream);
+    if (bn == 64) launch_cfg<64, 64>(p, stream);
     else if (bm == 128 && bn == 160) launch_cfg<128, 160>(p, stream);
     else if (bm == 128 && bn == 128) launch_cfg<128, 128>(p, stream);
     else if (bm == 64 && bn == 160) launch_cfg<64, 160>(p, stream);
@@ -1515,6 +964,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, bn);
+        t_last_kernel = intern_name(std::string(t_last_kernel) + "+splitk_reduce_kernel");
     }
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }

@@ -9,10 +9,9 @@
 // pixel chunks per image: aim at ~2048 blocks (x 4 channel slabs x n images), at least 8 pixels per chunk, at most 256 chunks
 static inline int gn_num_chunks(int n_img, int HW) {
     // workgroups per launch, measured (profiles/README.md): 512 is best at UNet batch 2 (GroupNorm 0.92 -> 0.74 ms per forward),
-    // 1024 at UNet batch 16 (1.51 -> 1.40 ms), 2048 for the 512x512 VAE tensors; LD_GN_BLOCKS overrides (A/B knob)
-    static const int env_target = getenv("LD_GN_BLOCKS") ? atoi(getenv("LD_GN_BLOCKS")) : 0;
+    // 1024 at UNet batch 16 (1.51 -> 1.40 ms), 2048 for the 512x512 VAE tensors
     const long long px = (long long)(n_img < 1 ? 1 : n_img) * HW;   // (sized by pixels: a batch-1 VAE image is one huge tensor)
-    const int target = env_target ? env_target : (px <= 8192 ? 512 : (px <= 131072 ? 1024 : 2048));
+    const int target = px <= 8192 ? 512 : (px <= 131072 ? 1024 : 2048);
     int p = target / (4 * (n_img < 1 ? 1 : n_img));
     if (p > HW / 8) p = HW / 8;
     if (p > 256) p = 256;
@@ -39,6 +38,7 @@ struct AttnParams {
     int causal = 0;              // key index <= query index only (CLIP text model, LD.py:4440-4446)
 };
 int attention_launch(const AttnParams& p, hipStream_t stream);
+const char* attention_last_kernel_name();   // instantiation the calling thread's last attention_launch dispatched
 
 // ---- misc.hip
 int ln_fold_launch(const half_t* W, int N, int K, const half_t* gamma, const half_t* beta, const half_t* bias, half_t* Wout, half_t* bout,

@@ -104,6 +104,13 @@ struct Timing {
     std::vector<hipEvent_t> ev;     // pool, pairs (start, stop)
     std::vector<int> cls;
     std::vector<std::string> desc;   // per launch, only when LD_PROFILE_DUMP is set
+    std::vector<const char*> kname;  // per launch: the kernel instantiation that ran (static strings)
+    std::vector<double> kflops;      // per launch: algorithmic FLOPs
+    struct PerKernel {
+        double ms = 0, flops = 0;
+        int launches = 0;
+    };
+    std::vector<std::pair<std::string, PerKernel>> per_kernel;   // filled by collect(), in first-seen order
     bool verbose = false;
     size_t used = 0;
     double ms[KC_COUNT] = {0}, flops[KC_COUNT] = {0};
@@ -120,6 +127,9 @@ struct Timing {
         used = 0;
         cls.clear();
         desc.clear();
+        kname.clear();
+        kflops.clear();
+        per_kernel.clear();
         verbose = getenv("LD_PROFILE_DUMP") != nullptr;
         for (int i = 0; i < KC_COUNT; ++i) ms[i] = flops[i] = 0, launches[i] = 0;
     }
@@ -128,6 +138,13 @@ struct Timing {
             float t = 0.f;
             (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]);
             ms[cls[i / 2]] += t;
+            const char* kn = i / 2 < kname.size() && kname[i / 2] ? kname[i / 2] : "?";
+            size_t j = 0;
+            while (j < per_kernel.size() && per_kernel[j].first != kn) ++j;
+            if (j == per_kernel.size()) per_kernel.push_back({kn, PerKernel()});
+            per_kernel[j].second.ms += t;
+            per_kernel[j].second.flops += i / 2 < kflops.size() ? kflops[i / 2] : 0.0;
+            per_kernel[j].second.launches += 1;
             if (verbose && i / 2 < desc.size()) fprintf(stderr, "[ld_profile] %8.1f us  %s\n", t * 1e3, desc[i / 2].c_str());
         }
     }
@@ -163,11 +180,13 @@ struct Exec {
         }
         timing->flops[c] += fl;
         timing->launches[c] += nl;
+        timing->kflops.push_back(fl);
         (void)hipEventRecord(timing->next(), stream);
     }
-    void t_end() {
+    void t_end(const char* kernel_name = "misc") {
         if (timing == nullptr || dry) return;
         (void)hipEventRecord(timing->next(), stream);
+        timing->kname.push_back(kernel_name);
     }
 
     void gemm(GemmParams p) {
@@ -182,7 +201,7 @@ struct Exec {
         t_begin(p.conv && p.ksize == 3 ? KC_CONV3 : KC_GEMM, fl, 1, p.conv ? (p.ksize == 3 ? "conv3" : "conv1") : (p.act == 2 ? "geglu" : "gemm"),
                 p.M, p.N, p.K, p.batch);
         note(gemm_launch(p, stream));
-        t_end();
+        t_end(gemm_last_kernel_name());
     }
     void groupnorm(const half_t* x1, int C1, const half_t* x2, int C2, int n, int HW, const half_t* g, const half_t* b, float eps,
                    int silu, half_t* y) {
@@ -191,14 +210,14 @@ struct Exec {
         launches += 2;
         t_begin(KC_GNORM, 0.0, 2, "groupnorm", n, HW, C1 + C2, silu);
         if (!dry && status == LD_OK) note(groupnorm_launch(x1, C1, x2, C2, n, HW, g, b, eps, silu, y, ws, stream));
-        t_end();
+        t_end("gn_stats_kernel+gn_apply_kernel");
         arena->release(m);
     }
     void layernorm(const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int C) {
         launches += 1;
         t_begin(KC_LNORM, 0.0, 1, "layernorm", rows, C);
         if (!dry && status == LD_OK) note(layernorm_launch(x, g, b, y, rows, C, 1e-5f, stream));
-        t_end();
+        t_end("layernorm_kernel");
     }
     void attention(const AttnParams& p) {
         const double fl = 4.0 * p.B * p.H * (double)p.Lq * p.Lk * p.d;
@@ -206,6 +225,6 @@ struct Exec {
         launches += 1;
         t_begin(KC_ATTN, fl, 1, "attention", (long long)p.B * p.H, p.Lq, p.Lk, p.d);
         if (!dry && status == LD_OK) note(attention_launch(p, stream));
-        t_end();
+        t_end(attention_last_kernel_name());
     }
 };

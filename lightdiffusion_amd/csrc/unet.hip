@@ -481,7 +481,7 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
     ex.launches += 1;
     ex.t_begin(KC_MISC, 0.0, 1);
     if (!dry) ex.note(timestep_embed_launch(sigma, u->log_sigmas, 1000, n, mc, temb, nullptr, stream));
-    ex.t_end();
+    ex.t_end("timestep_embed_kernel");
     half_t* e1 = ar.halfs((size_t)n * ted);
     R.linear(temb, mc, u->te0_w, u->te0_b, nullptr, e1, n, ted, mc, 1);
     half_t* semb = ar.halfs((size_t)n * ted);
@@ -534,7 +534,7 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
         ex.flops += 2.0 * n * h * w * mc * 9.0 * c.in_channels;
         ex.t_begin(KC_MISC, 2.0 * n * h * w * mc * 9.0 * c.in_channels, 1);
         if (!dry) ex.note(small_conv_in_launch(a, stream));
-        ex.t_end();
+        ex.t_end("small_conv_in_kernel");
         f = {o, mc, h, w};
         hs.push_back(f);
     }
@@ -562,7 +562,7 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
         ex.flops += 2.0 * n * f.H * f.W * f.C * 9.0 * c.out_channels;
         ex.t_begin(KC_MISC, 2.0 * n * f.H * f.W * f.C * 9.0 * c.out_channels, 1);
         if (!dry) ex.note(small_conv_out_launch(a, stream));
-        ex.t_end();
+        ex.t_end("small_conv_out_kernel");
     }
     u->last_launches = ex.launches;
     u->last_flops = ex.flops;
@@ -596,8 +596,7 @@ int ld_unet_create(const ld_unet_config* cfg, ld_unet** out) {
             ls[i] = (float)log(sqrt((1.0 - ac) / ac));
         }
     }
-    static const bool no_fold = getenv("LD_UNET_NO_LN_FOLD") != nullptr;   // A/B knob: keep the stand-alone LayerNorm launches
-    u->ln_fold = !no_fold && gemm_ln_fold_available();
+    u->ln_fold = gemm_ln_fold_available();
     if (u->ln_fold && u->fold_bytes > 0 && hipMalloc((void**)&u->fold_base, u->fold_bytes) != hipSuccess) {
         u->pt.destroy();
         delete u;
@@ -756,6 +755,18 @@ int ld_unet_profile(ld_unet* u, const float* x, const float* sigma, float* out, 
         ms[i] = u->timing.ms[i];
         flops[i] = u->timing.flops[i];
         launches[i] = u->timing.launches[i];
+    }
+    return LD_OK;
+}
+
+int ld_unet_profile_kernels(const ld_unet* u, char* buf, size_t buf_bytes) {
+    if (u == nullptr || buf == nullptr || buf_bytes == 0) return LD_ERR_ARG;
+    size_t off = 0;
+    buf[0] = 0;
+    for (const auto& kv : u->timing.per_kernel) {
+        const int w = snprintf(buf + off, buf_bytes - off, "%s\t%d\t%.6f\t%.0f\n", kv.first.c_str(), kv.second.launches, kv.second.ms, kv.second.flops);
+        if (w < 0 || (size_t)w >= buf_bytes - off) return LD_ERR_ARG;   // buffer too small
+        off += (size_t)w;
     }
     return LD_OK;
 }

@@ -166,6 +166,16 @@ class MI355XUNet:
                   "ld_unet_profile")
         return {k: (ms[i], fl[i], nl[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
 
+    def profile_kernels(self) -> dict:
+        """Per kernel instantiation of the last `profile()` call: {name: (ms, flops, launches)}."""
+        buf = C.create_string_buffer(1 << 16)
+        check(lib().ld_unet_profile_kernels(self._h, buf, len(buf)), "ld_unet_profile_kernels")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms, fl = line.split("\t")
+            out[name] = (float(ms), float(fl), int(n))
+        return out
+
     # -- the reference's plugin seam
     def _sync_context(self, ctx: torch.Tensor, n: int, h: int, w: int, token=None) -> None:
         """Make the resident cross-attention K / V^T those of `ctx`.  The reference re-concatenates the context every step

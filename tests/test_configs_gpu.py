@@ -355,7 +355,7 @@ def test_lora_merged_unet_and_clip_match_reference():
     unet.set_context(g["ctx"])
     den = unet.forward(g["x"].to(DEV), g["sigma"].to(DEV)).cpu()
     assert rel_l2(den, g["denoised"]) < UNET_TOL
-    inter = clip.cond_stage_model(g["tokens"], intermediate_output=-2)[1].cpu()
+    inter = clip.text_model(g["tokens"], intermediate_output=-2)[1].cpu()
     assert rel_l2(inter, g["clip_inter_m2"]) < 5e-3
     # without the LoRA the same stack is measurably different (the fixture is not a no-op)
     model0, clip0, _ = loader.load_checkpoint(dict(sd))
