@@ -54,6 +54,7 @@ struct GemmParams {
     float ln_inv_c = 0.f, ln_eps = 0.f;
     const float* ln_wsum = nullptr;  // per output feature: sum_k of the folded weight row ([N], or [M] when ln_swapped)
     int ln_swapped = 0;
+    int dbg = 0;                 // A/B build only (LD_AB_BUILD): ablation switches of the v5 kernel (timing runs, wrong results)
 };
 
 bool gemm_ln_fold_available();   // the kernels that implement stat_out / ln_stat are the ones gemm_launch will pick

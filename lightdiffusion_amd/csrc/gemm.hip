@@ -777,6 +777,400 @@ __global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
     epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid, scratch);
 }
 
+// =====================================================================================================================
+// v5: one 256 x 320 tile per workgroup, 8 waves (4 x 2, wave tile 64 x 160), 32-wide K steps in a 4-stage LDS-DMA ring, and the
+// two wave groups (waves 0-3 / 4-7: the two waves of every SIMD) run HALF A STEP APART:
+//     group 0:  | read k   | MFMA k   | read k+1 | MFMA k+1 | ...
+//     group 1:  | (idle)   | read k   | MFMA k   | read k+1 | ...           ('|' = one s_barrier joining all 8 waves)
+// so in every interval one wave of each SIMD issues 40 MFMAs (640 cycles) while its partner issues the 14 fragment reads
+// of its next step and its share of the LDS-DMA for the step after next (4-5 one-KB pieces).  Fragments are single-buffered:
+// the overlap comes from the partner wave, not from register double-buffering (160 accumulator + 56 fragment VGPRs at two
+// waves per SIMD).  Against the 128 x 160 tile of v3 a step moves half the LDS-DMA pieces and 0.35 instead of 0.45
+// fragment reads per MFMA, and nothing of the staging sits in front of the issuing wave's own MFMAs.
+//   step k lives in stage k % 4; group 0 reads it in interval 2k, group 1 in 2k+1; it is overwritten (step k+4) from
+//   interval 2k+2 on (three steps = 110 KB per CU in flight), and every wave waits for its own pieces of step k+1 (counted vmcnt) before the barrier that ends its
+//   read phase k — hence before anybody reads step k+1.
+// LDS rows are 64 bytes (4 chunks); chunk c of row r sits at physical chunk c ^ g[(r >> 2) & 3], g = {0, 2, 3, 1}: with the
+// lane groups ds_read_b128 is served in ({0-3, 12-15, 20-27}, ...) the 16 lanes of a group then hit 16 distinct 16-byte slots.
+// Epilogue: per wave, 16-row strips staged two at a time in the (then quiet) ring (rows padded to 328 bytes), 16-byte coalesced
+// stores of 320-byte row segments with the same fused bias / row vector / activation / GEGLU / residual / LN-fold math as v3.
+// Requirements (gemm_launch checks them): N % 320 == 0, K % 32 == 0, every split-K slice >= 2 steps, no ln_swapped.
+// =====================================================================================================================
+constexpr int V5_BM = 256, V5_BN = 320, V5_BK = 32, V5_NST = 4;
+constexpr int V5_A_BYTES = V5_BM * 64, V5_STAGE_BYTES = (V5_BM + V5_BN) * 64;
+constexpr int V5_EPI_LD = 164;                       // halfs per staged row: 320 data bytes + 8 pad (ds_write_b64 conflict-free)
+constexpr int V5_EPI_BYTES = 16 * V5_EPI_LD * 2;     // one 16-row strip of a wave
+constexpr int V5_SWZ = 0x78;                         // g[x] = (0x78 >> 2x) & 3 = {0, 2, 3, 1}
+
+// one 16-row x 160-column strip of a wave's tile: staged fp16 values -> fused epilogue -> 16-byte global stores
+__device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* Cs, int z, int m_base, int n_base, int lane, int part) {
+    if (p.act == 2) {   // GEGLU: the wave's 160 columns are one [80 value | 80 gate] block -> 80 outputs
+        uint4 rba[3], rbg[3], rres[3];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int q = lane + it * 64;
+            const int row = q / 10, cc = q - row * 10;
+            const int m = m_base + row, nv = n_base + cc * 8;
+            const bool ok = q < 160 && m < p.M;
+            rba[it] = ok ? ld16(p.bias_n + nv) : zero16();
+            rbg[it] = ok ? ld16(p.bias_n + nv + 80) : zero16();
+            rres[it] = (ok && p.R != nullptr) ? ld16(p.R + (long long)z * p.sR + (long long)m * p.ldr + n_base / 2 + cc * 8) : zero16();
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int q = lane + it * 64;
+            const int row = q / 10, cc = q - row * 10;
+            const int m = m_base + row;
+            if (q < 160 && m < p.M) {
+                float a[8], g[8], ba[8], bg[8], r[8];
+                unpack8(ld16(Cs + row * V5_EPI_LD + cc * 8), a);
+                unpack8(ld16(Cs + row * V5_EPI_LD + 80 + cc * 8), g);
+                unpack8(rba[it], ba);
+                unpack8(rbg[it], bg);
+                unpack8(rres[it], r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = (a[j] + ba[j]) * gelu_f(g[j] + bg[j]) + r[j];
+                st16(p.C + (long long)z * p.sC + (long long)m * p.ldc + n_base / 2 + cc * 8, pack8(a));
+            }
+        }
+        return;
+    }
+    const bool hb = p.bias_n != nullptr, hv = p.rowvec != nullptr, hr = p.R != nullptr;
+    uint4 rb[5], rv[5], rres[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int q = lane + it * 64;
+        const int row = q / 20, cc = q - row * 20;
+        const int m = m_base + row, n = n_base + cc * 8;
+        const bool ok = m < p.M;
+        rb[it] = (ok && hb) ? ld16(p.bias_n + n) : zero16();
+        rv[it] = (ok && hv) ? ld16(p.rowvec + (long long)(m / p.rows_per_vec) * p.ldrv + n) : zero16();
+        rres[it] = (ok && hr) ? ld16(p.R + (long long)z * p.sR + (long long)m * p.ldr + n) : zero16();
+    }
+    float s1[5], s2[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+        const int q = lane + it * 64;
+        const int row = q / 20, cc = q - row * 20;
+        const int m = m_base + row, n = n_base + cc * 8;
+        s1[it] = s2[it] = 0.f;
+        if (m < p.M) {
+            float v[8], b[8], e[8], r[8];
+            unpack8(ld16(Cs + row * V5_EPI_LD + cc * 8), v);
+            unpack8(rb[it], b);
+            unpack8(rv[it], e);
+            unpack8(rres[it], r);
+            const float bm = p.bias_m != nullptr ? (float)p.bias_m[m] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = v[j] + b[j] + bm + e[j];
+                if (p.act == 1) t = silu_f(t);
+                else if (p.act == 3) t = quick_gelu_f(t);
+                v[j] = t + r[j];
+            }
+            const uint4 packed = pack8(v);
+            st16(p.C + (long long)z * p.sC + (long long)m * p.ldc + n, packed);
+            if (p.stat_out != nullptr) {   // LN-fold producer: row statistics of what was actually stored (the fp16 values)
+                float f[8];
+                unpack8(packed, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s1[it] += f[j];
+                    s2[it] += f[j] * f[j];
+                }
+            }
+        }
+    }
+    if (p.stat_out != nullptr) {   // chunk partials -> LDS (the strip has been consumed) -> one lane per row sums them in chunk order
+        float* sc = reinterpret_cast<float*>(Cs);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int q = lane + it * 64;
+            sc[q * 2] = s1[it];
+            sc[q * 2 + 1] = s2[it];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 16 && m_base + lane < p.M) {
+            float a = 0.f, b = 0.f;
+            for (int c = 0; c < 20; ++c) {
+                a += sc[(lane * 20 + c) * 2];
+                b += sc[(lane * 20 + c) * 2 + 1];
+            }
+            float* o = p.stat_out + ((long long)part * p.M + m_base + lane) * 2;
+            o[0] = a;
+            o[1] = b;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+template <bool CONV>
+__global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
+    constexpr int TM = 4, TN = 10;
+    __shared__ __attribute__((aligned(16))) char smem5[V5_NST * V5_STAGE_BYTES];
+    static_assert(8 * 2 * V5_EPI_BYTES <= V5_NST * V5_STAGE_BYTES, "epilogue staging must fit in the ring");
+    __shared__ __attribute__((aligned(16))) float ln_mu[V5_BM], ln_rs[V5_BM];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool grp1 = wid >= 4;
+    const int wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 160;
+    const int z = blockIdx.z;
+    const int tiles_m = (p.M + V5_BM - 1) / V5_BM, tiles_n = p.N / V5_BN;
+    const int tiles = tiles_m * tiles_n;
+    const int splitk = p.splitk > 1 ? p.splitk : 1;
+    int bid = xcd_remap(blockIdx.x, tiles * splitk);
+    const int ks = bid / tiles;
+    bid -= ks * tiles;
+    const int tn_i = bid % tiles_n, tm_i = bid / tiles_n;
+    const int m0 = tm_i * V5_BM, n0 = tn_i * V5_BN;
+    const int KT = p.K / V5_BK;
+    const int kt_begin = (int)((long long)ks * KT / splitk), kt_end = (int)((long long)(ks + 1) * KT / splitk);
+    const int nk = kt_end - kt_begin;                              // >= 2 (gemm_launch)
+
+    const half_t* Ab = p.A + (long long)z * p.sA;
+    const half_t* Wb = p.W + (long long)z * p.sW;
+    const half_t* zp = reinterpret_cast<const half_t*>(g_zero_row);
+    const int Cin = p.C1 + p.C2;
+
+    // ---- loader state: 2 A pieces and 2 (waves 4-7) or 3 (waves 0-3) B pieces per wave and step; a piece = 16 rows x 64 bytes
+    const int prow = lane >> 2;                                    // row inside a piece (piece rows start at multiples of 16)
+    const int lchunk = (lane & 3) ^ ((V5_SWZ >> (2 * ((prow >> 2) & 3))) & 3);   // logical chunk this lane fetches
+    const int a_row0 = wid * 32 + prow;                            // + 16 for the second piece
+    const half_t* a_ptr[2];
+    unsigned a_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + a_row0 + i * 16;
+        a_ptr[i] = zp;
+        a_off[i] = CONV ? 0u : (unsigned)(((long long)(m < p.M ? m : p.M - 1) * p.lda + lchunk * 8) * 2);
+    }
+    const half_t* a_base = Ab + (long long)kt_begin * V5_BK;        // wave-uniform (plain GEMM)
+    int seg_left = 0;
+    int k_issue = kt_begin * V5_BK;                                 // K index of the next step to issue
+    auto conv_seek = [&](int k0) {
+        const int tap = k0 / Cin;
+        const int c0 = k0 - tap * Cin;
+        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+        const bool second = c0 >= p.C1;
+        const half_t* src = second ? p.A2 : Ab;
+        const int Cs = second ? p.C2 : p.C1;
+        const int cl = second ? c0 - p.C1 : c0;
+        seg_left = ((second ? Cin : p.C1) - c0) / V5_BK;
+        const int hw = p.Ho * p.Wo;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + a_row0 + i * 16;
+            const int mm = m < p.M ? m : 0;
+            const int img = mm / hw, rem = mm - img * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+            const bool ok = m < p.M && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv && tap < p.ksize * p.ksize;
+            int sy = iy, sx = ix;
+            if (p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws) {
+                sy = iy >> 1;
+                sx = ix >> 1;
+            } else if (p.Hv != p.Hs || p.Wv != p.Ws) {
+                sy = (int)((long long)iy * p.Hs / p.Hv);
+                sx = (int)((long long)ix * p.Ws / p.Wv);
+            }
+            a_ptr[i] = ok ? src + (((long long)img * p.Hs + sy) * p.Ws + sx) * Cs + cl + lchunk * 8 : zp + lchunk * 8;
+        }
+    };
+    unsigned b_off[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int piece = i < 2 ? wid * 2 + i : 16 + (wid & 3);
+        const int row = piece * 16 + prow;
+        const int n = n0 + row < p.n_valid ? n0 + row : p.n_valid - 1;
+        b_off[i] = (unsigned)(((long long)n * p.ldw + lchunk * 8) * 2);
+    }
+    const half_t* b_base = Wb + (long long)kt_begin * V5_BK;        // wave-uniform
+
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem5);
+    unsigned st_issue = 0;                                          // byte offset of the stage the next issued step goes to
+    auto issue = [&]() {
+        const unsigned As = smem_base + st_issue + (unsigned)(wid * 2) * 1024u;
+        const unsigned Bs = smem_base + st_issue + (unsigned)V5_A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (CONV) glds16(a_ptr[i], As + (unsigned)i * 1024u);
+            else glds16s(a_off[i], a_base, As + (unsigned)i * 1024u);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16s(b_off[i], b_base, Bs + (unsigned)(wid * 2 + i) * 1024u);
+        if (!grp1) glds16s(b_off[2], b_base, Bs + (unsigned)(16 + wid) * 1024u);
+        k_issue += V5_BK;
+        if (CONV) {
+            if (--seg_left <= 0) {
+                conv_seek(k_issue);
+            } else {
+                a_ptr[0] += V5_BK;
+                a_ptr[1] += V5_BK;
+            }
+        } else {
+            a_base += V5_BK;
+        }
+        b_base += V5_BK;
+        st_issue = st_issue == (unsigned)((V5_NST - 1) * V5_STAGE_BYTES) ? 0u : st_issue + (unsigned)V5_STAGE_BYTES;
+    };
+    // "my pieces of every step but the n newest ones issued have landed" (in-order completion; 5 or 4 pieces per step and wave)
+    auto wait_all_but = [&](int n) {
+        if (!grp1) {
+            if (n >= 2) wait_vmcnt<10>();
+            else if (n == 1) wait_vmcnt<5>();
+            else wait_vmcnt<0>();
+        } else {
+            if (n >= 2) wait_vmcnt<8>();
+            else if (n == 1) wait_vmcnt<4>();
+            else wait_vmcnt<0>();
+        }
+    };
+    if (CONV) conv_seek(k_issue);
+
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment read bases (bytes into stage 0): A rows wm0 + 16 i + fr, B rows wn0 + 16 j + fr; (row >> 2) & 3 == (fr >> 2) & 3
+    const unsigned rchunk = (unsigned)(fq ^ ((V5_SWZ >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
+    const char* rdA = smem5 + (wm0 + fr) * 64 + rchunk;
+    const char* rdB = smem5 + V5_A_BYTES + (wn0 + fr) * 64 + rchunk;
+    int st_read = 0;                                                // stage index of the step this wave reads next
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    half8 fa[TM], fb[TN];
+
+    // ---- prologue: steps 0 .. 2 in flight, step 0 landed and published, group 1 one barrier behind
+    issue();
+    issue();
+    if (nk > 2) issue();
+    if (p.ln_stat != nullptr) ln_prepare<V5_BM, V5_BN>(p, ln_mu, ln_rs, z, m0, n0, tid);   // (the loop's barriers publish it)
+    wait_all_but(nk > 2 ? 2 : 1);
+    __builtin_amdgcn_s_barrier();
+    if (grp1) __builtin_amdgcn_s_barrier();
+
+    for (int k = 0; k < nk; ++k) {
+        // ------------------------------------------------ read phase (the partner wave of this SIMD is in its MFMA phase)
+#ifdef LD_AB_BUILD
+        if (p.dbg & 32) __builtin_amdgcn_s_setprio(2);
+        if (k + 3 < nk && !(p.dbg & 1) && !(p.dbg & 8)) issue();
+        if (!(p.dbg & 2) || k == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = as_half8(ld16(rdB + j * 1024));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = as_half8(ld16(rdA + i * 1024));
+        }
+        if (p.dbg & 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 3 < nk && !(p.dbg & 1)) issue();
+        }
+        if (p.dbg & 32) __builtin_amdgcn_s_setprio(0);
+#else
+        if (k + 3 < nk) issue();                                    // step k+3 -> the stage step k-1 left (both groups are done with it)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = as_half8(ld16(rdB + j * 1024));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = as_half8(ld16(rdA + i * 1024));
+#endif
+        {
+            const int d = st_read == V5_NST - 1 ? -(V5_NST - 1) * V5_STAGE_BYTES : V5_STAGE_BYTES;
+            rdA += d;
+            rdB += d;
+            st_read = st_read == V5_NST - 1 ? 0 : st_read + 1;
+        }
+        // my pieces of step k+1 have landed (steps k+2, k+3, if issued, may stay in flight); the barrier publishes them
+#ifdef LD_AB_BUILD
+        if (p.dbg & 1) wait_vmcnt<0>();
+        else
+#endif
+            wait_all_but(k + 3 < nk ? 2 : (k + 2 < nk ? 1 : 0));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ------------------------------------------------ MFMA phase (the partner reads / stages)
+#ifdef LD_AB_BUILD
+        if (!(p.dbg & 16))
+#endif
+            __builtin_amdgcn_s_setprio(1);
+#ifdef LD_AB_BUILD
+        if (p.dbg & 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[0], acc[0][j], 0, 0, 0);
+        } else
+#endif
+        {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (!grp1) __builtin_amdgcn_s_barrier();                        // group 0 waits out group 1's last MFMA phase: every wave ran 2 nk + 2 barriers
+
+    const int m_w = m0 + wm0, n_w = n0 + wn0;
+    if (splitk > 1) {
+        float* part = p.partial + (long long)ks * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_w + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n_w + j * 16 + fq * 4;
+                if (m < p.M) {
+                    f32x4 v = acc[i][j];
+                    v *= p.alpha;
+                    *reinterpret_cast<f32x4*>(part + (long long)m * p.N + n) = v;
+                }
+            }
+        }
+        return;
+    }
+    // the ring is quiet (every wave is past its last fragment read and DMA wait): each wave stages two 16-row strips at a time in
+    // its own 10.5 KB of it, so at most half of the accumulators are live next to the epilogue's prefetch registers
+    half_t* Cs = reinterpret_cast<half_t*>(smem5 + wid * 2 * V5_EPI_BYTES);
+    const int part = tn_i * 2 + (wid & 1);                          // LN-fold statistics: one part per 160-column half tile
+    const bool ln = p.ln_stat != nullptr;
+    auto stage = [&](auto I, half_t* dst) {                         // literal strip index: the accumulators stay in registers
+        constexpr int i = decltype(I)::value;
+        // LN-fold consumer: acc <- rstd * (acc - mu * wsum) in fp32, strip by strip (keeps the live registers low)
+        const float mu = ln ? ln_mu[wm0 + i * 16 + fr] : 0.f, rs = ln ? ln_rs[wm0 + i * 16 + fr] : 1.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 v = acc[i][j];
+            if (ln) {
+                const f32x4 ws = *reinterpret_cast<const f32x4*>(p.ln_wsum + n_w + j * 16 + fq * 4);
+                v = (v - mu * ws) * rs;
+            }
+            half4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)(v[r] * p.alpha);
+            *reinterpret_cast<half4*>(dst + fr * V5_EPI_LD + j * 16 + fq * 4) = h;
+        }
+    };
+    half_t* Cs1 = Cs + 16 * V5_EPI_LD;
+    stage(std::integral_constant<int, 0>{}, Cs);
+    stage(std::integral_constant<int, 1>{}, Cs1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: the strips are complete
+    __builtin_amdgcn_sched_barrier(0);
+    v5_epilogue_strip(p, Cs, z, m_w, n_w, lane, part);
+    v5_epilogue_strip(p, Cs1, z, m_w + 16, n_w, lane, part);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // strips consumed before the next pair overwrites them
+    __builtin_amdgcn_sched_barrier(0);
+    stage(std::integral_constant<int, 2>{}, Cs);
+    stage(std::integral_constant<int, 3>{}, Cs1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    v5_epilogue_strip(p, Cs, z, m_w + 32, n_w, lane, part);
+    v5_epilogue_strip(p, Cs1, z, m_w + 48, n_w, lane, part);
+}
+
 // split-K second pass: sum the fp32 slabs and run the same epilogue
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, int bn) {
     const int out_n = p.act == 2 ? p.N / 2 : p.N;
@@ -863,11 +1257,14 @@ void launch_cfg(const GemmParams& p, hipStream_t s) {
 #ifdef LD_AB_BUILD
 // tuning hook of the A/B build (tools/gemm_sweep.py): force tile height / split-K for every following launch; 0 = automatic.
 // Not part of the shipped library: `make AB=1` builds libld_mi355x_ab.so with it.
-static int g_force_bm = 0, g_force_sk = 0;
+static int g_force_bm = 0, g_force_sk = 0, g_no_v5 = 0;
 extern "C" void ld_debug_gemm_override(int bm, int splitk) {
     g_force_bm = bm;
     g_force_sk = splitk;
 }
+extern "C" void ld_debug_gemm_no_v5(int off) { g_no_v5 = off; }
+static int g_v5_dbg = 0;
+extern "C" void ld_debug_gemm_v5_dbg(int bits) { g_v5_dbg = bits; }   // 1: no DMA issue in the loop, 2: no fragment reads, 4: 4 of 40 MFMAs
 #endif
 
 bool gemm_ln_fold_available() { return true; }
@@ -876,6 +1273,7 @@ const char* gemm_last_kernel_name() { return t_last_kernel; }
 int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     GemmParams p = pin;
 #ifdef LD_AB_BUILD
+    p.dbg = g_v5_dbg;
     if (g_force_bm) p.bm = g_force_bm;
     if (g_force_sk) p.splitk = g_force_sk;
 #endif
@@ -897,6 +1295,52 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (p.R != nullptr && (p.ldr & 7)) return LD_ERR_SHAPE;
 
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
+    // ---- v5 (256 x 320 tile, 8 waves, staggered wave groups): whenever its tiles (x an optional split over K) fill the chip
+    {
+        // measured per shape against v3 (tools/gemm5_ab.py, profiles/README.md): +9..23 % on the K >= 2880 convs, +4..12 % at K = 1280,
+        // even at K = 640, -5..-16 % at K = 320 (one workgroup per CU: nothing overlaps a short tile's prologue and epilogue)
+        const bool shape_ok = !p.ln_swapped && p.bm == 0 && (p.bn == 0 || p.bn == 160) && p.N % V5_BN == 0 && p.K % V5_BK == 0 &&
+                              p.K >= (p.act == 2 ? 1280 : 640) && (p.n_valid == p.N || p.n_valid <= 0 || p.n_valid > p.N) && p.splitk == 0 &&
+                              p.M >= 1024;
+#ifdef LD_AB_BUILD
+        if (shape_ok && !g_no_v5) {
+#else
+        if (shape_ok) {
+#endif
+            const long long t5 = (long long)((p.M + V5_BM - 1) / V5_BM) * (p.N / V5_BN) * p.batch;
+            const bool ln = p.stat_out != nullptr || p.ln_stat != nullptr;
+            int sk5 = 1;
+            if (t5 < 192 && !ln && p.batch == 1 && p.partial != nullptr && p.K >= 5120) {
+                sk5 = (int)((256 + t5 - 1) / t5);
+                const int cap = p.K / 2560;
+                if (sk5 > cap) sk5 = cap;
+                while (sk5 > 1 && (size_t)sk5 * p.M * p.N * sizeof(float) > p.partial_bytes) --sk5;
+            }
+            if (t5 * sk5 >= 192 && !(p.act == 2 && p.stat_out != nullptr)) {
+                if (p.stat_parts_out != nullptr) *p.stat_parts_out = 2 * (p.N / V5_BN);
+                p.splitk = sk5;
+                p.bn = 160;
+                if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
+                dim3 grid((unsigned)(((p.M + V5_BM - 1) / V5_BM) * (p.N / V5_BN) * sk5), 1, p.batch);
+                if (p.conv) {
+                    t_last_kernel = "gemm5_kernel<256,320,conv>";
+                    hipLaunchKernelGGL((gemm5_kernel<true>), grid, dim3(512), 0, stream, p);
+                } else {
+                    t_last_kernel = "gemm5_kernel<256,320,plain>";
+                    hipLaunchKernelGGL((gemm5_kernel<false>), grid, dim3(512), 0, stream, p);
+                }
+                if (sk5 > 1) {
+                    const int out_n = p.act == 2 ? p.N / 2 : p.N;
+                    const long long total = (long long)p.M * (out_n / 8);
+                    int blocks = (int)((total + 255) / 256);
+                    if (blocks > 2048) blocks = 2048;
+                    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, 160);
+                    t_last_kernel = intern_name(std::string(t_last_kernel) + "+splitk_reduce_kernel");
+                }
+                return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+            }
+        }
+    }
     int bn = p.bn ? p.bn : gemm_pick_bn(p.N);
     // Skinny plain GEMMs (the batch-1 step's M = 128..2048 projections): with <= 128 tiles of 64 x 160 most CUs idle while
     // each busy one streams 28.7 KB per slab through its one LDS-DMA path; 64 x 64 tiles spread the same work over 2.5x more CUs

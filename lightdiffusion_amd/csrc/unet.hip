@@ -663,7 +663,7 @@ int ld_unet_reserve(ld_unet* u, int max_n, int max_h, int max_w, int max_tok) {
     const size_t tpad = (size_t)u->ctx_tpad;
     size_t ctxb = ((size_t)max_n * tpad * u->cfg.context_dim * sizeof(half_t) + 255) / 256 * 256;
     for (const StW& s : u->st) ctxb += 2 * (((size_t)max_n * tpad * s.c * sizeof(half_t) + 255) / 256 * 256);
-    u->splitk_bytes = (size_t)64 << 20;
+    u->splitk_bytes = (size_t)96 << 20;
     u->ws_bytes = act + ctxb + u->splitk_bytes + 4096;
     if (hipMalloc((void**)&u->ws_base, u->ws_bytes) != hipSuccess) {
         u->ws_base = nullptr;

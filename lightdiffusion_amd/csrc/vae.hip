@@ -450,7 +450,7 @@ int ld_vae_reserve(ld_vae* v, int max_b, int max_h, int max_w) {
         if (pe > peak) peak = pe;
     }
     const size_t act = (peak + 4095) / 4096 * 4096;
-    v->splitk_bytes = (size_t)64 << 20;
+    v->splitk_bytes = (size_t)96 << 20;
     v->ws_bytes = act + v->splitk_bytes + 4096;
     if (hipMalloc((void**)&v->ws_base, v->ws_bytes) != hipSuccess) {
         v->ws_base = nullptr;

@@ -224,3 +224,86 @@ def test_linear_quick_gelu(ops):
     ref = F.linear(x.float(), w.float(), b.float())
     ref = ref * torch.sigmoid(1.702 * ref)
     assert rel_l2(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act="quick_gelu").float().cpu(), ref) < TOL
+
+
+# ------------------------------------------------------------------ the 256 x 320 tile kernel (gemm5_kernel): shapes that fill the chip
+@pytest.mark.parametrize("M,N,K,bias,res,act", [
+    (65536, 320, 320, True, True, "none"), (50000, 640, 320, True, False, "none"), (65536, 320, 1280, True, True, "none"),
+    (16384, 1280, 640, False, False, "silu"), (33000, 640, 64, True, False, "none"), (4096, 10240, 96, True, False, "quick_gelu")])
+def test_linear_big_tiles(ops, M, N, K, bias, res, act):
+    x, w = r16((M, K), 81), r16((N, K), 82, 1 / math.sqrt(K))
+    b = r16((N,), 83, 0.1) if bias else None
+    r = r16((M, N), 84) if res else None
+    y = ops.linear(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), None if r is None else r.to(DEV), act=act)
+    ref = F.linear(x.float().to(DEV), w.float().to(DEV), None if b is None else b.float().to(DEV))      # fp32 reference, evaluated on the device for speed
+    if act == "silu":
+        ref = F.silu(ref)
+    elif act == "quick_gelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if r is not None:
+        ref = ref + r.float().to(DEV)
+    assert rel_l2(y.float().cpu(), ref.cpu()) < TOL
+    # spot rows against a CPU fp32 evaluation (independent of the device's fp32 GEMM)
+    rows = torch.tensor([0, 1, 255, 256, M // 2 + 3, M - 257, M - 1])
+    ref_cpu = F.linear(x[rows].float(), w.float(), None if b is None else b.float())
+    if act == "silu":
+        ref_cpu = F.silu(ref_cpu)
+    elif act == "quick_gelu":
+        ref_cpu = ref_cpu * torch.sigmoid(1.702 * ref_cpu)
+    if r is not None:
+        ref_cpu = ref_cpu + r[rows].float()
+    assert rel_l2(y[rows].float().cpu(), ref_cpu) < TOL
+
+
+@pytest.mark.parametrize("M,C", [(65536, 320), (16500, 640)])
+def test_geglu_big_tiles(ops, M, C):
+    x, w, b = r16((M, C), 85), r16((8 * C, C), 86, 1 / math.sqrt(C)), r16((8 * C,), 87, 0.1)
+    y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act="geglu")
+    a, g = F.linear(x.float().to(DEV), w.float().to(DEV), b.float().to(DEV)).chunk(2, dim=-1)
+    assert rel_l2(y.float().cpu(), (a * F.gelu(g)).cpu()) < TOL
+    rows = torch.tensor([0, 17, 255, 256, M - 1])
+    a, g = F.linear(x[rows].float(), w.float(), b.float()).chunk(2, dim=-1)
+    assert rel_l2(y[rows].float().cpu(), a * F.gelu(g)) < TOL
+
+
+@pytest.mark.parametrize("n,h,w,c1,c2,cout,stride,out_hw,rv,res", [
+    (16, 64, 64, 320, 0, 320, 1, None, True, True),        # level-0 ResBlock conv at UNet batch 16: 256 tiles, no split
+    (8, 64, 64, 320, 0, 320, 1, None, False, False),       # 128 tiles -> split-K 2 + reduce
+    (16, 32, 32, 640, 320, 640, 1, None, True, False),     # two-source concat (skip connection), 128 tiles x split 2
+    (16, 16, 16, 1280, 0, 1280, 1, (32, 32), False, False),  # nearest 2x upsample fused into the loader
+    (16, 64, 64, 320, 0, 320, 2, None, False, False),      # stride 2 (Downsample1)
+    (3, 61, 67, 64, 64, 640, 1, None, True, True)])        # ragged M (not a multiple of 256), image edges everywhere
+def test_conv3x3_big_tiles(ops, n, h, w, c1, c2, cout, stride, out_hw, rv, res):
+    x1 = r16((n, c1, h, w), 91)
+    x2 = r16((n, c2, h, w), 92) if c2 else None
+    cin = c1 + c2
+    wt, b = r16((cout, cin, 3, 3), 93, 1 / math.sqrt(9 * cin)), r16((cout,), 94, 0.1)
+    xin = x1.float().to(DEV) if x2 is None else torch.cat([x1.float(), x2.float()], 1).to(DEV)
+    if out_hw is not None:
+        xin = F.interpolate(xin, size=out_hw, mode="nearest")
+    ref = F.conv2d(xin, wt.float().to(DEV), b.float().to(DEV), stride=stride, padding=1)
+    rowvec = r16((n, cout), 95) if rv else None
+    if rv:
+        ref = ref + rowvec.float().to(DEV)[:, :, None, None]
+    r = r16(tuple(ref.shape), 96) if res else None
+    if res:
+        ref = ref + r.float().to(DEV)
+    wp = ops.repack_conv_weight(wt.to(DEV))
+    y = ops.conv2d(nhwc(x1).to(DEV), wp, b.to(DEV), 3, stride, None if x2 is None else nhwc(x2).to(DEV), out_hw,
+                   None if rowvec is None else rowvec.to(DEV), None if r is None else nhwc(r).to(DEV))
+    assert rel_l2(nchw(y.float().cpu()), ref.cpu()) < TOL
+
+
+def test_linear_ln_big_tiles(ops):
+    """LN fold through the 256 x 320 tile kernel: producer statistics per 160-column half tile, consumer epilogue."""
+    M, C, N = 65536, 320, 640
+    g = torch.Generator().manual_seed(97)
+    x = (torch.randn(M, C, generator=g) * 2.0 + 0.7).half()
+    wp, bp = (torch.randn(C, C, generator=g) / math.sqrt(C)).half(), (0.1 * torch.randn(C, generator=g)).half()
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).half(), (0.1 * torch.randn(C, generator=g)).half()
+    w, b = (torch.randn(N, C, generator=g) / math.sqrt(C)).half(), (0.1 * torch.randn(N, generator=g)).half()
+    t, y = ops.linear_ln(x.to(DEV), wp.to(DEV), bp.to(DEV), gamma.to(DEV), beta.to(DEV), w.to(DEV), b.to(DEV))
+    t_ref = F.linear(x.float().to(DEV), wp.float().to(DEV), bp.float().to(DEV))
+    assert rel_l2(t.float().cpu(), t_ref.cpu()) < TOL
+    y_ref = F.linear(F.layer_norm(t.float(), (C,), gamma.float().to(DEV), beta.float().to(DEV), 1e-5), w.float().to(DEV), b.float().to(DEV))
+    assert rel_l2(y.float().cpu(), y_ref.cpu()) < 3e-3
