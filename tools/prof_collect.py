@@ -1,0 +1,73 @@
+"""Summarise rocprofv3 output directories into the small tracked files under profiles/ (run after a gpurun profiling call).
+
+  python tools/prof_collect.py stats <rocprof dir> profiles/<name>_kernel_stats.csv
+  python tools/prof_collect.py pmc <tag> profiles/<name>_pmc.csv <rocprof dir> [<rocprof dir> ...]
+
+`stats`: copies the largest *_kernel_stats.csv (the process that ran the GPU work).
+`pmc`:   per kernel (short names as bench.py prints them) the mean of every collected counter per dispatch, and rewrites
+         profiles/pmc_traffic.json[tag][kernel] = {"fetch_bytes", "write_bytes", ...} with the gfx950 FETCH_SIZE correction
+         (x2: the counter tallies 128-byte requests as 64 bytes, MI355X_MICROARCH.md 'HBM'); FETCH_SIZE / WRITE_SIZE are in KiB."""
+import collections, csv, glob, json, os, re, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short_name(k):
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"gemm(\d)_kernel<(\d+), (\d+), (true|false)(?:, \d+)?>", k)
+    if m:
+        return f"gemm{m.group(1)}_kernel<{m.group(2)},{m.group(3)},{'conv' if m.group(4) == 'true' else 'plain'}>"
+    m = re.match(r"gemm5_kernel<(true|false)>", k)
+    if m:
+        return f"gemm5_kernel<256,320,{'conv' if m.group(1) == 'true' else 'plain'}>"
+    m = re.match(r"flash_attn2_kernel<(\d+), (true|false), (\d+), \d+>", k)
+    if m:
+        return f"flash_attn2_kernel<{m.group(1)},{'masked' if m.group(2) == 'true' else 'plain'},{m.group(3)}>"
+    return re.sub(r"\(.*$", "", k)
+
+
+def biggest(d, pattern):
+    files = glob.glob(os.path.join(d, "**", pattern), recursive=True)
+    if not files:
+        raise SystemExit(f"no {pattern} under {d}")
+    return max(files, key=os.path.getsize)
+
+
+def main():
+    mode = sys.argv[1]
+    if mode == "stats":
+        src = biggest(sys.argv[2], "*_kernel_stats.csv")
+        shutil.copyfile(src, sys.argv[3])
+        print("copied", src, "->", sys.argv[3])
+        return
+    tag, out = sys.argv[2], sys.argv[3]
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for d in sys.argv[4:]:
+        with open(biggest(d, "*_counter_collection.csv")) as f:
+            for row in csv.DictReader(f):
+                a = acc[short_name(row["Kernel_Name"])][row["Counter_Name"]]
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+    with open(out, "w") as f:
+        f.write("kernel,counter,mean_per_dispatch,dispatches\n")
+        for k in sorted(acc):
+            for c in sorted(acc[k]):
+                f.write(f'"{k}",{c},{acc[k][c][0] / acc[k][c][1]:.6g},{acc[k][c][1]}\n')
+    tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    db = json.load(open(tp)) if os.path.exists(tp) else {}
+    t = db.setdefault(tag, {})
+    for k in acc:
+        e = {}
+        if "FETCH_SIZE" in acc[k]:
+            e["fetch_bytes"] = 2.0 * 1024.0 * acc[k]["FETCH_SIZE"][0] / acc[k]["FETCH_SIZE"][1]     # KiB, x2 (gfx950)
+        if "WRITE_SIZE" in acc[k]:
+            e["write_bytes"] = 1024.0 * acc[k]["WRITE_SIZE"][0] / acc[k]["WRITE_SIZE"][1]
+        if e:
+            e["hbm_bytes_per_launch"] = e.get("fetch_bytes", 0.0) + e.get("write_bytes", 0.0)
+            t.setdefault(k, {}).update(e)
+    json.dump(db, open(tp, "w"), indent=1, sort_keys=True)
+    print("wrote", out, "and", tp)
+
+
+if __name__ == "__main__":
+    main()
