@@ -488,3 +488,37 @@ int bislerp_launch(const float* x, float* tmp, float* y, int n, int c, int h, in
                        h_new, 0);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MLP-out fold (unet.hip): the feed-forward's second Linear and the SpatialTransformer's proj_out are back-to-back affine maps
+//   t' = ff W2^T + b2 + t;   out = t' Wpo^T + bpo + x      (LD.py:3924-3928, 4259-4262)
+// so   out = [ff | t] [Wpo W2 | Wpo]^T + (Wpo b2 + bpo) + x   is ONE contraction over K = 4C + C with a two-source A operand.
+// This kernel derives W'[n][0:4C] = sum_c Wpo[n][c] W2[c][:], W'[n][4C:5C] = Wpo[n][:] and b'[n] once per weight load (fp32
+// accumulation in a fixed order, one rounding to fp16).
+namespace {
+__global__ __launch_bounds__(256) void mlp_out_fold_kernel(const half_t* __restrict__ Wpo, const half_t* __restrict__ W2, const half_t* __restrict__ b2,
+                                                           const half_t* __restrict__ bpo, int C, half_t* __restrict__ Wout, half_t* __restrict__ bout) {
+    extern __shared__ float wrow[];          // Wpo[n][:] as fp32
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int H = 4 * C, K = 5 * C;
+    for (int c = tid; c < C; c += 256) wrow[c] = (float)Wpo[(long long)n * C + c];
+    __syncthreads();
+    for (int k = tid; k < H; k += 256) {     // consecutive threads read consecutive k of every W2 row: coalesced
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += wrow[c] * (float)W2[(long long)c * H + k];
+        Wout[(long long)n * K + k] = (half_t)s;
+    }
+    for (int c = tid; c < C; c += 256) Wout[(long long)n * K + H + c] = Wpo[(long long)n * C + c];
+    if (tid == 0) {
+        float s = (float)bpo[n];
+        for (int c = 0; c < C; ++c) s += wrow[c] * (float)b2[c];
+        bout[n] = (half_t)s;
+    }
+}
+}  // namespace
+
+int mlp_out_fold_launch(const half_t* Wpo, const half_t* W2, const half_t* b2, const half_t* bpo, int C, half_t* Wout, half_t* bout, hipStream_t stream) {
+    if (Wpo == nullptr || W2 == nullptr || b2 == nullptr || bpo == nullptr || Wout == nullptr || bout == nullptr || C <= 0) return LD_ERR_ARG;
+    hipLaunchKernelGGL(mlp_out_fold_kernel, dim3(C), dim3(256), (size_t)C * sizeof(float), stream, Wpo, W2, b2, bpo, C, Wout, bout);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}

@@ -8,6 +8,12 @@
 #include "runtime.h"
 #include "../../include/ld_mi355x.h"
 
+#ifdef LD_AB_BUILD
+// A/B build only: executor-level switches for same-process A/B timing (tools/ab_unet.py); bit 0: no MLP-out fold
+static int g_unet_dbg = 0;
+extern "C" void ld_debug_unet_flags(int bits) { g_unet_dbg = bits; }
+#endif
+
 namespace {
 
 struct ResW {
@@ -21,6 +27,8 @@ struct StW {
     // ld_unet::fold_base) and their fp32 row sums, for the projections that consume LN1 (q|k, v), LN2 (q of attn2), LN3 (GEGLU)
     size_t f_qk_w = 0, f_v_w = 0, f_q2_w = 0, f_ff1_w = 0, f_qk_b = 0, f_v_b = 0, f_q2_b = 0, f_ff1_b = 0, f_qk_s = 0, f_v_s = 0, f_q2_s = 0,
            f_ff1_s = 0;
+    // MLP-out fold: [Wpo W2 | Wpo] ([C][5C]) and Wpo b2 + bpo — ff.net.2 and proj_out run as ONE two-source contraction
+    size_t f_mo_w = 0, f_mo_b = 0;
     int gn_g, gn_b, pin_w, pin_b, ln1_g, ln1_b, q1_w, k1_w, v1_w, o1_w, o1_b, ln2_g, ln2_b, q2_w, k2_w, v2_w, o2_w, o2_b, ln3_g,
         ln3_b, ff1_w, ff1_b, ff2_w, ff2_b, pout_w, pout_b;
 };
@@ -157,6 +165,8 @@ int add_st(ld_unet* u, const std::string& p, int c) {
         s.f_v_s = take(C * sizeof(float));
         s.f_q2_s = take(C * sizeof(float));
         s.f_ff1_s = take(8 * C * sizeof(float));
+        s.f_mo_w = take(5 * C * C * sizeof(half_t));
+        s.f_mo_b = take(C * sizeof(half_t));
     }
     u->st.push_back(s);
     return (int)u->st.size() - 1;
@@ -425,8 +435,26 @@ struct Run {
             if (fold) ln_args(p, s.f_ff1_s);
             ex.gemm(p);
         }
-        linear(ff, 4 * C, s.ff2_w, s.ff2_b, t, t, M, C, 4 * C);
-        linear(t, C, s.pout_w, s.pout_b, x, out, M, C, C);
+#ifdef LD_AB_BUILD
+        if (fold && !(g_unet_dbg & 1)) {
+#else
+        if (fold) {
+#endif
+            // out = x + proj_out(t + ff2(ff)) as one contraction over [ff | t] (K = 5C) against the folded [Wpo W2 | Wpo] (misc.hip)
+            GemmParams p;
+            p.conv = 1; p.ksize = 1;
+            p.A = ff; p.A2 = t; p.C1 = 4 * C; p.C2 = C;
+            p.Hs = p.Hv = p.Ho = H; p.Ws = p.Wv = p.Wo = W; p.stride = 1;
+            p.W = reinterpret_cast<const half_t*>(fb + s.f_mo_w); p.ldw = 5 * C;
+            p.M = M; p.N = C; p.K = 5 * C;
+            p.bias_n = reinterpret_cast<const half_t*>(fb + s.f_mo_b);
+            p.R = x; p.ldr = C;
+            p.C = out; p.ldc = C;
+            ex.gemm(p);
+        } else {
+            linear(ff, 4 * C, s.ff2_w, s.ff2_b, t, t, M, C, 4 * C);
+            linear(t, C, s.pout_w, s.pout_b, x, out, M, C, C);
+        }
         ar.release(mk);
         return {out, C, H, W};
     }
@@ -445,6 +473,7 @@ int fold_layernorms(ld_unet* u, hipStream_t stream) {
         if (st == LD_OK) st = ln_fold_launch(u->pt.ptr(s.v1_w), C, C, u->pt.ptr(s.ln1_g), u->pt.ptr(s.ln1_b), nullptr, H(s.f_v_w), H(s.f_v_b), F(s.f_v_s), stream);
         if (st == LD_OK) st = ln_fold_launch(u->pt.ptr(s.q2_w), C, C, u->pt.ptr(s.ln2_g), u->pt.ptr(s.ln2_b), nullptr, H(s.f_q2_w), H(s.f_q2_b), F(s.f_q2_s), stream);
         if (st == LD_OK) st = ln_fold_launch(u->pt.ptr(s.ff1_w), 8 * C, C, u->pt.ptr(s.ln3_g), u->pt.ptr(s.ln3_b), u->pt.ptr(s.ff1_b), H(s.f_ff1_w), H(s.f_ff1_b), F(s.f_ff1_s), stream);
+        if (st == LD_OK) st = mlp_out_fold_launch(u->pt.ptr(s.pout_w), u->pt.ptr(s.ff2_w), u->pt.ptr(s.ff2_b), u->pt.ptr(s.pout_b), C, H(s.f_mo_w), H(s.f_mo_b), stream);
         if (st != LD_OK) return st;
     }
     u->fold_dirty = false;
