@@ -905,6 +905,69 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
     }
 }
 
+// tail shared by the 256 x 320 tile kernels (v5 / v6): split-K slab store, or the staged fused epilogue (two 16-row strips at a
+// time through this wave's 10.5 KB of the — by now quiet — LDS ring)
+__device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][10], char* smem5, const float* ln_mu, const float* ln_rs, int z, int m0,
+                                          int n0, int wm0, int wn0, int wid, int lane, int ks, int splitk, int tn_i) {
+    constexpr int TM = 4, TN = 10;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int m_w = m0 + wm0, n_w = n0 + wn0;
+    if (splitk > 1) {
+        float* part = p.partial + (long long)ks * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_w + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n_w + j * 16 + fq * 4;
+                if (m < p.M) {
+                    f32x4 v = acc[i][j];
+                    v *= p.alpha;
+                    *reinterpret_cast<f32x4*>(part + (long long)m * p.N + n) = v;
+                }
+            }
+        }
+        return;
+    }
+    // the ring is quiet (every wave is past its last fragment read and DMA wait): each wave stages two 16-row strips at a time in
+    // its own 10.5 KB of it, so at most half of the accumulators are live next to the epilogue's prefetch registers
+    half_t* Cs = reinterpret_cast<half_t*>(smem5 + wid * 2 * V5_EPI_BYTES);
+    const int part = tn_i * 2 + (wid & 1);                          // LN-fold statistics: one part per 160-column half tile
+    const bool ln = p.ln_stat != nullptr;
+    auto stage = [&](auto I, half_t* dst) {                         // literal strip index: the accumulators stay in registers
+        constexpr int i = decltype(I)::value;
+        // LN-fold consumer: acc <- rstd * (acc - mu * wsum) in fp32, strip by strip (keeps the live registers low)
+        const float mu = ln ? ln_mu[wm0 + i * 16 + fr] : 0.f, rs = ln ? ln_rs[wm0 + i * 16 + fr] : 1.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 v = acc[i][j];
+            if (ln) {
+                const f32x4 ws = *reinterpret_cast<const f32x4*>(p.ln_wsum + n_w + j * 16 + fq * 4);
+                v = (v - mu * ws) * rs;
+            }
+            half4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)(v[r] * p.alpha);
+            *reinterpret_cast<half4*>(dst + fr * V5_EPI_LD + j * 16 + fq * 4) = h;
+        }
+    };
+    half_t* Cs1 = Cs + 16 * V5_EPI_LD;
+    stage(std::integral_constant<int, 0>{}, Cs);
+    stage(std::integral_constant<int, 1>{}, Cs1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: the strips are complete
+    __builtin_amdgcn_sched_barrier(0);
+    v5_epilogue_strip(p, Cs, z, m_w, n_w, lane, part);
+    v5_epilogue_strip(p, Cs1, z, m_w + 16, n_w, lane, part);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // strips consumed before the next pair overwrites them
+    __builtin_amdgcn_sched_barrier(0);
+    stage(std::integral_constant<int, 2>{}, Cs);
+    stage(std::integral_constant<int, 3>{}, Cs1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    v5_epilogue_strip(p, Cs, z, m_w + 32, n_w, lane, part);
+    v5_epilogue_strip(p, Cs1, z, m_w + 48, n_w, lane, part);
+}
+
 template <bool CONV>
 __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
     constexpr int TM = 4, TN = 10;
@@ -924,7 +987,11 @@ __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
     const int ks = bid / tiles;
     bid -= ks * tiles;
     const int tn_i = bid % tiles_n, tm_i = bid / tiles_n;
+#ifdef LD_AB_BUILD
+    const int m0 = (p.dbg & 64) ? 0 : tm_i * V5_BM, n0 = (p.dbg & 64) ? 0 : tn_i * V5_BN;
+#else
     const int m0 = tm_i * V5_BM, n0 = tn_i * V5_BN;
+#endif
     const int KT = p.K / V5_BK;
     const int kt_begin = (int)((long long)ks * KT / splitk), kt_end = (int)((long long)(ks + 1) * KT / splitk);
     const int nk = kt_end - kt_begin;                              // >= 2 (gemm_launch)
@@ -1114,61 +1181,182 @@ __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
     }
     if (!grp1) __builtin_amdgcn_s_barrier();                        // group 0 waits out group 1's last MFMA phase: every wave ran 2 nk + 2 barriers
 
-    const int m_w = m0 + wm0, n_w = n0 + wn0;
-    if (splitk > 1) {
-        float* part = p.partial + (long long)ks * p.M * p.N;
+    v5_finish(p, acc, smem5, ln_mu, ln_rs, z, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
+}
+
+// =====================================================================================================================
+// v6: 3x3 stride-1 convolution on the v5 skeleton (256 x 320 tile, 8 waves, two wave groups half a step apart), with the A
+// operand taken from a HALO tile: the 256 output pixels of a tile are 256 / W whole image rows, so for one 32-channel slab the
+// (256 / W + 2) x (W + 2) input pixels they touch are copied to LDS ONCE (LDS-DMA, image border = zero page) and the nine taps
+// read their fragments from it at literal offsets — K runs slab-major, tap-minor.  Against v5's implicit im2col the A share of
+// the LDS-DMA falls from 16 pieces per 32-wide step to ceil(HP / 16) pieces per NINE steps (W = 64: 25), i.e. 36 -> 22.8 pieces
+// per step in total, and every input byte leaves L2 once per tile instead of nine times.
+// Weights stay in the checkpoint-derived [Cout][tap][Cin] order: the B pointer just walks  +Cin per tap, +32 - 8 Cin per slab.
+// The halo is double-buffered (slab s+1 is fetched during the nine steps of slab s); its rows are 64 bytes, unswizzled: the
+// four A fragment reads of a step are 2-way bank-conflicted (of 14 reads; the LDS port is ~25 % busy).
+// Requirements (gemm_launch): ksize 3, stride 1, pad 1, no resize, Wo == W in {16, 32, 64, 128}, Ho * Wo % 256 == 0,
+// C1 % 32 == 0, C2 % 32 == 0, N % 320 == 0; a split over K is a split over slabs.
+// =====================================================================================================================
+template <int W>
+__global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
+    constexpr int TM = 4, TN = 10;
+    constexpr int TR = 256 / W, HW2 = W + 2, HP = (TR + 2) * HW2;      // tile rows, halo row pitch (pixels), halo pixels
+    constexpr int NH = ((HP + 15) / 16 + 7) / 8;                      // halo LDS-DMA pieces per wave and slab (uniform: spare pieces copy zeros)
+    constexpr int HBYTES = NH * 8 * 1024;                              // one halo buffer
+    constexpr int BSTAGE = V5_BN * 64, NSTB = 4;                       // B ring: 4 stages of 320 rows x 64 bytes
+    constexpr int RING0 = 2 * HBYTES;                                  // byte offset of the B ring
+    __shared__ __attribute__((aligned(16))) char smem5[2 * HBYTES + NSTB * BSTAGE];
+    static_assert(2 * HBYTES + NSTB * BSTAGE <= 163840, "LDS");
+    static_assert(8 * 2 * V5_EPI_BYTES <= 2 * HBYTES + NSTB * BSTAGE, "epilogue staging must fit");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool grp1 = wid >= 4;
+    const int wm = wid >> 1;
+    const int wm0 = wm * 64, wn0 = (wid & 1) * 160;
+    const int tiles_m = p.M / V5_BM, tiles_n = p.N / V5_BN;
+    const int tiles = tiles_m * tiles_n;
+    const int splitk = p.splitk > 1 ? p.splitk : 1;
+    int bid = xcd_remap(blockIdx.x, tiles * splitk);
+    const int ks = bid / tiles;
+    bid -= ks * tiles;
+    const int tn_i = bid % tiles_n, tm_i = bid / tiles_n;
+    const int m0 = tm_i * V5_BM, n0 = tn_i * V5_BN;
+    const int Cin = p.C1 + p.C2;
+    const int NS = Cin / 32;                                           // channel slabs
+    const int s_begin = (int)((long long)ks * NS / splitk), s_end = (int)((long long)(ks + 1) * NS / splitk);
+    const int nk = (s_end - s_begin) * 9;                              // 32-wide steps of this workgroup (>= 9)
+
+    const half_t* zp = reinterpret_cast<const half_t*>(g_zero_row);
+    const int HWo = p.Ho * p.Wo;
+    const int img = m0 / HWo, row0 = (m0 - img * HWo) / W;             // this tile = image rows row0 .. row0 + TR - 1 of image img
+
+    // ---- halo loader state: piece j of this wave covers halo pixels (wid + 8 j) * 16 .. + 15; lane -> (pixel, 16-byte chunk)
+    int hpix[NH];                                                      // source pixel index inside the image, or -1 (border / spare)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m_w + i * 16 + fr;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n_w + j * 16 + fq * 4;
-                if (m < p.M) {
-                    f32x4 v = acc[i][j];
-                    v *= p.alpha;
-                    *reinterpret_cast<f32x4*>(part + (long long)m * p.N + n) = v;
-                }
-            }
-        }
-        return;
+    for (int j = 0; j < NH; ++j) {
+        const int hp = (wid + 8 * j) * 16 + (lane >> 2);
+        const int hy = hp / HW2, hx = hp - hy * HW2;
+        const int iy = row0 + hy - 1, ix = hx - 1;
+        hpix[j] = (hp < HP && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)W) ? iy * W + ix : -1;
     }
-    // the ring is quiet (every wave is past its last fragment read and DMA wait): each wave stages two 16-row strips at a time in
-    // its own 10.5 KB of it, so at most half of the accumulators are live next to the epilogue's prefetch registers
-    half_t* Cs = reinterpret_cast<half_t*>(smem5 + wid * 2 * V5_EPI_BYTES);
-    const int part = tn_i * 2 + (wid & 1);                          // LN-fold statistics: one part per 160-column half tile
-    const bool ln = p.ln_stat != nullptr;
-    auto stage = [&](auto I, half_t* dst) {                         // literal strip index: the accumulators stay in registers
-        constexpr int i = decltype(I)::value;
-        // LN-fold consumer: acc <- rstd * (acc - mu * wsum) in fp32, strip by strip (keeps the live registers low)
-        const float mu = ln ? ln_mu[wm0 + i * 16 + fr] : 0.f, rs = ln ? ln_rs[wm0 + i * 16 + fr] : 1.f;
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem5);
+    auto issue_halo = [&](int s, int buf) {                            // channel slab s (32 channels of the concatenated input) -> halo buffer buf
+        const int c0 = s * 32;
+        const bool second = c0 >= p.C1;
+        const half_t* src = (second ? p.A2 : p.A) + (long long)img * p.Hs * W * (second ? p.C2 : p.C1) + (second ? c0 - p.C1 : c0) + (lane & 3) * 8;
+        const int Cs = second ? p.C2 : p.C1;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            f32x4 v = acc[i][j];
-            if (ln) {
-                const f32x4 ws = *reinterpret_cast<const f32x4*>(p.ln_wsum + n_w + j * 16 + fq * 4);
-                v = (v - mu * ws) * rs;
-            }
-            half4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)(v[r] * p.alpha);
-            *reinterpret_cast<half4*>(dst + fr * V5_EPI_LD + j * 16 + fq * 4) = h;
+        for (int j = 0; j < NH; ++j) {
+            const half_t* g = hpix[j] >= 0 ? src + (long long)hpix[j] * Cs : zp;
+            glds16(g, smem_base + (unsigned)(buf * HBYTES) + (unsigned)(wid + 8 * j) * 1024u);
         }
     };
-    half_t* Cs1 = Cs + 16 * V5_EPI_LD;
-    stage(std::integral_constant<int, 0>{}, Cs);
-    stage(std::integral_constant<int, 1>{}, Cs1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: the strips are complete
-    __builtin_amdgcn_sched_barrier(0);
-    v5_epilogue_strip(p, Cs, z, m_w, n_w, lane, part);
-    v5_epilogue_strip(p, Cs1, z, m_w + 16, n_w, lane, part);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // strips consumed before the next pair overwrites them
-    __builtin_amdgcn_sched_barrier(0);
-    stage(std::integral_constant<int, 2>{}, Cs);
-    stage(std::integral_constant<int, 3>{}, Cs1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    v5_epilogue_strip(p, Cs, z, m_w + 32, n_w, lane, part);
-    v5_epilogue_strip(p, Cs1, z, m_w + 48, n_w, lane, part);
+    // ---- B loader state (as v5): 2 pieces per wave and step, a third for waves 0-3
+    const int prow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((V5_SWZ >> (2 * ((prow >> 2) & 3))) & 3);
+    unsigned b_off[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int piece = i < 2 ? wid * 2 + i : 16 + (wid & 3);
+        const int n = n0 + piece * 16 + prow;
+        b_off[i] = (unsigned)(((long long)n * p.ldw + lchunk * 8) * 2);
+    }
+    const half_t* b_base = p.W + (long long)s_begin * 32;              // step (slab s_begin, tap 0); wave-uniform
+    int b_tap = 0;
+    unsigned st_issue = 0;                                             // byte offset (inside the B ring) of the stage the next step goes to
+    auto issue_b = [&]() {
+        const unsigned Bs = smem_base + (unsigned)RING0 + st_issue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16s(b_off[i], b_base, Bs + (unsigned)(wid * 2 + i) * 1024u);
+        if (!grp1) glds16s(b_off[2], b_base, Bs + (unsigned)(16 + wid) * 1024u);
+        if (b_tap == 8) {
+            b_tap = 0;
+            b_base += 32 - 8 * Cin;
+        } else {
+            ++b_tap;
+            b_base += Cin;
+        }
+        st_issue = st_issue == (unsigned)((NSTB - 1) * BSTAGE) ? 0u : st_issue + (unsigned)BSTAGE;
+    };
+    // "every LDS-DMA of mine but the n newest steps' B pieces (+ the halo pieces when they sit among those) has landed"
+    auto wait_keep = [&](int steps, bool halo) {
+        if (!grp1) {
+            if (steps >= 2) { if (halo) wait_vmcnt<6 + NH>(); else wait_vmcnt<6>(); }
+            else if (steps == 1) { if (halo) wait_vmcnt<3 + NH>(); else wait_vmcnt<3>(); }
+            else wait_vmcnt<0>();
+        } else {
+            if (steps >= 2) { if (halo) wait_vmcnt<4 + NH>(); else wait_vmcnt<4>(); }
+            else if (steps == 1) { if (halo) wait_vmcnt<2 + NH>(); else wait_vmcnt<2>(); }
+            else wait_vmcnt<0>();
+        }
+    };
+
+    // ---- fragment read bases: A = halo pixel of output pixel (wm0 + 16 i + fr) at tap (0,0), B as v5
+    const int fr = lane & 15, fq = lane >> 4;
+    const int oyw = wm0 / W, oxw = wm0 - oyw * W;                      // first output pixel of this wave inside the tile
+    const char* rdA = smem5 + ((oyw * HW2 + oxw + fr) * 64 + fq * 16);
+    const unsigned rchunk = (unsigned)(fq ^ ((V5_SWZ >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
+    const char* rdB = smem5 + RING0 + (wn0 + fr) * 64 + rchunk;
+    int st_read = 0;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    half8 fa[TM], fb[TN];
+
+    // ---- prologue: halo of the first slab and B steps 0..2 in flight; step 0 + halo landed and published; group 1 one barrier behind
+    issue_halo(s_begin, 0);
+    issue_b();
+    issue_b();
+    issue_b();
+    wait_keep(2, false);
+    __builtin_amdgcn_s_barrier();
+    if (grp1) __builtin_amdgcn_s_barrier();
+
+    int k = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+        const int hb = (s - s_begin) & 1;
+        const char* rdAs = rdA + hb * HBYTES;
+#pragma unroll
+        for (int t = 0; t < 9; ++t, ++k) {
+            // ------------------------------------------------ read phase (the partner wave of this SIMD is in its MFMA phase)
+            if (t == 0 && s + 1 < s_end) issue_halo(s + 1, hb ^ 1);    // the other buffer was last read in slab s-1: free for everyone
+            if (k + 3 < nk) issue_b();
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = as_half8(ld16(rdB + j * 1024));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                // output pixel block i of this wave: 16 pixels of one image row; literal offset of its tap-(ky,kx) halo pixels
+                const int pi = i * 16;                                   // (wm0 % W + 16 i) stays inside the row: W % 16 == 0 and wm0 % 16 == 0
+                const int oy = (W >= 64) ? 0 : pi / W, ox = (W >= 64) ? pi : pi % W;
+                fa[i] = as_half8(ld16(rdAs + ((oy + t / 3) * HW2 + ox + t % 3) * 64));
+            }
+            {
+                const int d = st_read == NSTB - 1 ? -(NSTB - 1) * BSTAGE : BSTAGE;
+                rdB += d;
+                st_read = st_read == NSTB - 1 ? 0 : st_read + 1;
+            }
+            // my B pieces of step k+1 (and, from tap 2 on, the next slab's halo pieces) have landed; the barrier publishes them
+            wait_keep(k + 3 < nk ? 2 : (k + 2 < nk ? 1 : 0), t < 2 && s + 1 < s_end);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ------------------------------------------------ MFMA phase (the partner reads / stages)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (!grp1) __builtin_amdgcn_s_barrier();                            // group 0 waits out group 1's last MFMA phase
+    v5_finish(p, acc, smem5, nullptr, nullptr, 0, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue
@@ -1295,6 +1483,46 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (p.R != nullptr && (p.ldr & 7)) return LD_ERR_SHAPE;
 
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
+    // ---- v6 (halo-tile 3x3 convolution on the v5 skeleton): stride-1 convs whose tiles are whole image rows and fill the chip
+    if (p.conv && p.ksize == 3 && p.stride == 1 && (p.pad < 0 || p.pad == 1) && p.Hv == p.Hs && p.Wv == p.Ws && p.Ho == p.Hs && p.Wo == p.Ws &&
+        (p.Wo == 16 || p.Wo == 32 || p.Wo == 64 || p.Wo == 128) && (p.Ho * p.Wo) % V5_BM == 0 && p.C1 % 32 == 0 && p.C2 % 32 == 0 &&
+        p.N % V5_BN == 0 && p.bm == 0 && p.bn == 0 && p.splitk == 0 && p.batch == 1 && p.act != 2
+#ifdef LD_AB_BUILD
+        && !(g_no_v5 & 2)
+#endif
+    ) {
+        const long long t6 = (long long)(p.M / V5_BM) * (p.N / V5_BN);
+        const int NS = (p.C1 + p.C2) / 32;
+        int sk6 = 1;
+        if (t6 < 192 && p.partial != nullptr && p.K >= 5120) {
+            sk6 = (int)((256 + t6 - 1) / t6);
+            const int cap = p.K / 2560;
+            if (sk6 > cap) sk6 = cap;
+            if (sk6 > NS) sk6 = NS;
+            while (sk6 > 1 && (size_t)sk6 * p.M * p.N * sizeof(float) > p.partial_bytes) --sk6;
+        }
+        if (t6 * sk6 >= 192) {
+            p.splitk = sk6;
+            p.pad = 1;
+            p.n_valid = p.N;
+            dim3 grid((unsigned)(t6 * sk6), 1, 1);
+            t_last_kernel = "conv6_kernel<256,320,halo>";
+            switch (p.Wo) {
+                case 16: hipLaunchKernelGGL((conv6_kernel<16>), grid, dim3(512), 0, stream, p); break;
+                case 32: hipLaunchKernelGGL((conv6_kernel<32>), grid, dim3(512), 0, stream, p); break;
+                case 64: hipLaunchKernelGGL((conv6_kernel<64>), grid, dim3(512), 0, stream, p); break;
+                default: hipLaunchKernelGGL((conv6_kernel<128>), grid, dim3(512), 0, stream, p); break;
+            }
+            if (sk6 > 1) {
+                const long long total = (long long)p.M * (p.N / 8);
+                int blocks = (int)((total + 255) / 256);
+                if (blocks > 2048) blocks = 2048;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, 160);
+                t_last_kernel = intern_name(std::string(t_last_kernel) + "+splitk_reduce_kernel");
+            }
+            return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+        }
+    }
     // ---- v5 (256 x 320 tile, 8 waves, staggered wave groups): whenever its tiles (x an optional split over K) fill the chip
     {
         // measured per shape against v3 (tools/gemm5_ab.py, profiles/README.md): +9..23 % on the K >= 2880 convs, +4..12 % at K = 1280,
@@ -1303,7 +1531,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
                               p.K >= (p.act == 2 ? 1280 : 640) && (p.n_valid == p.N || p.n_valid <= 0 || p.n_valid > p.N) && p.splitk == 0 &&
                               p.M >= 1024;
 #ifdef LD_AB_BUILD
-        if (shape_ok && !g_no_v5) {
+        if (shape_ok && !(g_no_v5 & 1)) {
 #else
         if (shape_ok) {
 #endif

@@ -272,7 +272,11 @@ def test_geglu_big_tiles(ops, M, C):
     (16, 32, 32, 640, 320, 640, 1, None, True, False),     # two-source concat (skip connection), 128 tiles x split 2
     (16, 16, 16, 1280, 0, 1280, 1, (32, 32), False, False),  # nearest 2x upsample fused into the loader
     (16, 64, 64, 320, 0, 320, 2, None, False, False),      # stride 2 (Downsample1)
-    (3, 61, 67, 64, 64, 640, 1, None, True, True)])        # ragged M (not a multiple of 256), image edges everywhere
+    (3, 61, 67, 64, 64, 640, 1, None, True, True),         # ragged M (not a multiple of 256), image edges everywhere
+    (16, 64, 64, 640, 320, 320, 1, None, True, True),      # halo kernel, W = 64, two sources (output-block ResBlock conv1)
+    (64, 16, 16, 1280, 0, 1280, 1, None, False, True),     # halo kernel, W = 16: a tile is one whole 16x16 image
+    (4, 128, 128, 320, 0, 320, 1, None, True, False),      # halo kernel, W = 128 (hires latents): two image rows per tile
+    (16, 32, 32, 64, 0, 640, 1, None, False, False)])      # halo kernel, W = 32, two 32-channel slabs only
 def test_conv3x3_big_tiles(ops, n, h, w, c1, c2, cout, stride, out_hw, rv, res):
     x1 = r16((n, c1, h, w), 91)
     x2 = r16((n, c2, h, w), 92) if c2 else None

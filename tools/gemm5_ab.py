@@ -59,14 +59,16 @@ cases = [lin(65536, 320, 320, res=True), lin(65536, 320, 320), lin(65536, 640, 3
          lin(16384, 5120, 640, act=2), lin(16384, 1280, 640), lin(4096, 10240, 1280, act=2), lin(8192, 8000, 8192) if False else lin(8192, 8320, 8192),
          conv(16, 64, 320, 320, True), conv(16, 64, 640, 320), conv(16, 64, 960, 320), conv(16, 64, 640, 640), conv(16, 32, 1280, 1280),
          conv(16, 32, 640, 640), conv(16, 16, 1280, 1280)]
-print(f"{'shape':34s} {'v3 us':>9s} {'TF/s':>7s} {'v5 us':>9s} {'TF/s':>7s}  v3/v5")
+MODE = os.environ.get("AB_MODE", "v5")      # "v5": v3 vs (v5 + v6);  "v6": v5 (no halo kernel) vs v6
+OFF = 3 if MODE == "v5" else 2
+print(f"{'shape':34s} {'off us':>9s} {'TF/s':>7s} {'on us':>9s} {'TF/s':>7s}  off/on   ({MODE})")
 for fn, fl, name in cases:
     reps = max(3, min(50, int(2e-3 / (fl / 0.8e15)) + 1))
-    t = {0: [], 1: []}
+    t = {0: [], OFF: []}
     for _ in range(3):
-        for off in (1, 0):
+        for off in (OFF, 0):
             L.ld_debug_gemm_no_v5(off)
             t[off].append(graph_time(fn, reps))
     L.ld_debug_gemm_no_v5(0)
-    a, b = min(t[1]), min(t[0])
+    a, b = min(t[OFF]), min(t[0])
     print(f"{name:34s} {a * 1e3:9.1f} {fl / a / 1e9:7.0f} {b * 1e3:9.1f} {fl / b / 1e9:7.0f}  {a / b:5.2f}", flush=True)
