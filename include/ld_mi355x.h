@@ -116,6 +116,13 @@ int ld_op_linear(const void* x, const void* w, const void* bias, const void* res
 int ld_op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int w, int hv, int wv, int stride, int ksize,
                const void* wt, const void* bias, const void* rowvec, const void* residual, void* y, int cout,
                void* ws, size_t ws_bytes, void* stream);
+/* GroupNorm(32) + SiLU + 3x3 conv (stride 1, pad 1) over the channel concat of two NHWC sources — ResBlock1.in_layers /
+ * out_layers (LD.py:5224-5262).  Where the conv runs on the halo-tile kernel the normalisation is fused into its A operand
+ * (statistics pass only, no normalised tensor in HBM).  ws >= ld_op_groupnorm_conv_ws_bytes(...). */
+size_t ld_op_groupnorm_conv_ws_bytes(int c1, int c2, int n, int h, int w, int cout);
+int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int w, const void* gamma, const void* beta, float eps,
+                         const void* wt, const void* bias, const void* rowvec, const void* residual, void* y, int cout, void* ws,
+                         size_t ws_bytes, void* stream);
 int ld_op_repack_conv(const void* src_oihw, int dtype, int cout, int cin, void* dst, void* stream);
 /* GroupNorm(32) over the channel concat of two NHWC sources (+ optional SiLU); ws >= ld_op_groupnorm_ws_bytes */
 size_t ld_op_groupnorm_ws_bytes(int n, int hw);

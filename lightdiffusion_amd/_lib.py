@@ -68,6 +68,8 @@ SIGNATURES = {
     "ld_vae_last_flops": (C.c_double, [_P]),
     "ld_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _Z, _P]),
     "ld_op_conv": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
+    "ld_op_groupnorm_conv_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "ld_op_groupnorm_conv": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "ld_op_repack_conv": (_I, [_P, _I, _I, _I, _P, _P]),
     "ld_op_groupnorm_ws_bytes": (_Z, [_I, _I]),
     "ld_op_groupnorm": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P]),

@@ -85,6 +85,50 @@ int ld_op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int
     return gemm_launch(p, (hipStream_t)stream);
 }
 
+size_t ld_op_groupnorm_conv_ws_bytes(int c1, int c2, int n, int h, int w, int cout) {
+    const size_t C = (size_t)c1 + c2, HW = (size_t)h * w;
+    return align256(groupnorm_workspace_bytes(n, (int)HW)) + 2 * align256((size_t)n * C * sizeof(float)) + align256((size_t)n * HW * C * sizeof(half_t)) +
+           ((size_t)96 << 20);
+}
+
+int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int w, const void* gamma, const void* beta, float eps,
+                         const void* wt, const void* bias, const void* rowvec, const void* residual, void* y, int cout, void* ws, size_t ws_bytes,
+                         void* stream_) {
+    // GroupNorm(32) + SiLU + 3x3 convolution (stride 1, pad 1): the reference's ResBlock1.in_layers / out_layers (LD.py:5224-5262).
+    // On the halo-tile kernel the normalisation is fused into the convolution's A operand; otherwise two-pass GroupNorm, then the conv.
+    if (x1 == nullptr || gamma == nullptr || beta == nullptr || wt == nullptr || y == nullptr || ws == nullptr) return LD_ERR_ARG;
+    if (ws_bytes < ld_op_groupnorm_conv_ws_bytes(c1, c2, n, h, w, cout)) return LD_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int C = c1 + c2, HW = h * w;
+    char* q = (char*)ws;
+    float* part = (float*)q; q += align256(groupnorm_workspace_bytes(n, HW));
+    float* scale = (float*)q; q += align256((size_t)n * C * sizeof(float));
+    float* shift = (float*)q; q += align256((size_t)n * C * sizeof(float));
+    half_t* g = (half_t*)q; q += align256((size_t)n * HW * C * sizeof(half_t));
+    GemmParams p;
+    p.conv = 1; p.ksize = 3;
+    p.A = (const half_t*)x1; p.A2 = (const half_t*)x2; p.C1 = c1; p.C2 = c2;
+    p.Hs = p.Hv = p.Ho = h; p.Ws = p.Wv = p.Wo = w; p.stride = 1;
+    p.K = 9 * C; p.W = (const half_t*)wt; p.ldw = p.K;
+    p.M = n * HW; p.N = cout;
+    p.bias_n = (const half_t*)bias;
+    p.rowvec = (const half_t*)rowvec; p.rows_per_vec = HW; p.ldrv = cout;
+    p.R = (const half_t*)residual; p.ldr = cout;
+    p.C = (half_t*)y; p.ldc = cout;
+    p.partial = (float*)q; p.partial_bytes = (size_t)96 << 20;
+    if (gemm_conv_fuses_groupnorm(p)) {
+        int st = groupnorm_scale_shift_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, HW, (const half_t*)gamma, (const half_t*)beta, eps, part,
+                                              scale, shift, stream);
+        if (st != LD_OK) return st;
+        p.gn_scale = scale; p.gn_shift = shift; p.gn_silu = 1;
+        return gemm_launch(p, stream);
+    }
+    int st = groupnorm_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, HW, (const half_t*)gamma, (const half_t*)beta, eps, 1, g, part, stream);
+    if (st != LD_OK) return st;
+    p.A = g; p.A2 = nullptr; p.C1 = C; p.C2 = 0;
+    return gemm_launch(p, stream);
+}
+
 int ld_op_repack_conv(const void* src, int dtype, int cout, int cin, void* dst, void* stream) {
     return repack_conv3x3_launch(src, dtype == LD_F32, cout, cin, (half_t*)dst, (hipStream_t)stream);
 }

@@ -54,6 +54,11 @@ struct GemmParams {
     float ln_inv_c = 0.f, ln_eps = 0.f;
     const float* ln_wsum = nullptr;  // per output feature: sum_k of the folded weight row ([N], or [M] when ln_swapped)
     int ln_swapped = 0;
+    // ---- GroupNorm(+SiLU) fused into the A operand of the halo-tile convolution (v6 only; see gemm_conv_fuses_groupnorm):
+    //   the conv reads the RAW tensor and applies  y = x * scale[img][c] + shift[img][c]  (then SiLU) while the halo sits in LDS
+    const float* gn_scale = nullptr;   // [n_img][C1 + C2] fp32: rstd * gamma
+    const float* gn_shift = nullptr;   // [n_img][C1 + C2] fp32: beta - mean * rstd * gamma
+    int gn_silu = 0;
     int dbg = 0;                 // A/B build only (LD_AB_BUILD): ablation switches of the v5 kernel (timing runs, wrong results)
 };
 
@@ -64,3 +69,6 @@ const char* gemm_last_kernel_name();   // kernel instantiation the calling threa
 static inline int gemm_pick_bn(int N) { return (N % 160 == 0) ? 160 : 128; }
 
 int gemm_launch(const GemmParams& p, hipStream_t stream);
+// true when gemm_launch would run this convolution on the halo-tile kernel, i.e. when it can take gn_scale / gn_shift
+// (fill every other field first; gemm_launch rejects gn_scale on any other path)
+bool gemm_conv_fuses_groupnorm(const GemmParams& p);

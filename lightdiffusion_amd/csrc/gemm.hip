@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
 // Requirements (gemm_launch): ksize 3, stride 1, pad 1, no resize, Wo == W in {16, 32, 64, 128}, Ho * Wo % 256 == 0,
 // C1 % 32 == 0, C2 % 32 == 0, N % 320 == 0; a split over K is a split over slabs.
 // =====================================================================================================================
-template <int W>
+template <int W, bool GN>   // GN: GroupNorm (+SiLU) of the input fused into the halo (separate instantiation: the plain conv keeps its registers)
 __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     constexpr int TM = 4, TN = 10;
     constexpr int TR = 256 / W, HW2 = W + 2, HP = (TR + 2) * HW2;      // tile rows, halo row pitch (pixels), halo pixels
@@ -1207,6 +1207,14 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     constexpr int RING0 = 2 * HBYTES;                                  // byte offset of the B ring
     __shared__ __attribute__((aligned(16))) char smem5[2 * HBYTES + NSTB * BSTAGE];
     static_assert(2 * HBYTES + NSTB * BSTAGE <= 163840, "LDS");
+    static_assert(3 + NH <= 9, "fused GroupNorm: my pieces of the next slab are normalised in the read phase of tap 3");
+    // fused GroupNorm: every wave keeps the 32 scales + 32 shifts of the slab being normalised in 256 bytes of LDS.  Where the
+    // halo buffers and the B ring already take all 160 KB (W = 128) the tables live in spare piece slots of halo buffer 0 and the
+    // spare (all-zero) pieces of every wave are sent to the last slot instead
+    constexpr int HPIECES = (HP + 15) / 16;
+    constexpr bool TBL_IN_HALO = 2 * HBYTES + NSTB * BSTAGE + 2048 > 163840;
+    static_assert(!TBL_IN_HALO || NH * 8 - HPIECES >= 3, "two table slots and a dump slot");
+    __shared__ __attribute__((aligned(16))) float gn_lds[(GN && !TBL_IN_HALO) ? 8 * 64 : 4];
     static_assert(8 * 2 * V5_EPI_BYTES <= 2 * HBYTES + NSTB * BSTAGE, "epilogue staging must fit");
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1249,8 +1257,43 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < NH; ++j) {
             const half_t* g = hpix[j] >= 0 ? src + (long long)hpix[j] * Cs : zp;
-            glds16(g, smem_base + (unsigned)(buf * HBYTES) + (unsigned)(wid + 8 * j) * 1024u);
+            const int slot = (GN && TBL_IN_HALO && wid + 8 * j >= HPIECES) ? NH * 8 - 1 : wid + 8 * j;
+            glds16(g, smem_base + (unsigned)(buf * HBYTES) + (unsigned)slot * 1024u);
         }
+    };
+    // ---- fused GroupNorm (+SiLU) of the input (GN): y = x * scale[img][c] + shift[img][c], applied to the halo IN LDS, each lane on
+    // the 16-byte chunks it copied itself (so only its own DMA wait orders it).  The 32 scales and 32 shifts of a slab are fetched by
+    // ONE untracked load per lane (lane l: entry l of [scale | shift]) and parked in this wave's 256-byte LDS table.
+    // Border pixels stay zero: the convolution pads the NORMALISED tensor.
+    float gn_tbl = 0.f;
+    auto gn_load = [&](int s) {          // issued BEFORE the halo pieces of the same slab: their wait covers it (in-order completion)
+        const float* src = ((lane & 32) ? p.gn_shift : p.gn_scale) + (long long)img * Cin + s * 32 + (lane & 31);
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(gn_tbl) : "v"(src) : "memory");
+    };
+    float* const gn_mine = (TBL_IN_HALO ? reinterpret_cast<float*>(smem5 + HPIECES * 1024) : gn_lds) + wid * 64;
+    auto gn_apply_slab = [&](int buf) {
+        // runs at the head of a read phase, fenced off from the fragment reads behind it: the 56 fragment registers are dead there,
+        // so the temporaries below cost no accumulator spills.  All NH pieces in one go: their LDS reads overlap each other.
+        __builtin_amdgcn_sched_barrier(0);
+        gn_mine[lane] = gn_tbl;          // same wave reads it back: in-order LDS, no barrier
+        const float* tp = gn_mine + (lane & 3) * 8;
+        H8 io[NH];
+#pragma unroll
+        for (int j = 0; j < NH; ++j) io[j].u = ld16(smem5 + buf * HBYTES + (wid + 8 * j) * 1024 + lane * 16);
+        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(tp), sc1 = *reinterpret_cast<const f32x4*>(tp + 4);
+        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(tp + 32), sh1 = *reinterpret_cast<const f32x4*>(tp + 36);
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = (float)io[j].e[e] * (e < 4 ? sc0[e & 3] : sc1[e & 3]) + (e < 4 ? sh0[e & 3] : sh1[e & 3]);
+                if (p.gn_silu) v *= __builtin_amdgcn_rcpf(1.0f + __expf(-v));   // SiLU with v_rcp_f32 (1 ulp; rounded to fp16 anyway)
+                io[j].e[e] = (half_t)v;
+            }
+            if (hpix[j] >= 0) st16(smem5 + buf * HBYTES + (wid + 8 * j) * 1024 + lane * 16, io[j].u);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
     };
     // ---- B loader state (as v5): 2 pieces per wave and step, a third for waves 0-3
     const int prow = lane >> 2;
@@ -1308,11 +1351,13 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     half8 fa[TM], fb[TN];
 
     // ---- prologue: halo of the first slab and B steps 0..2 in flight; step 0 + halo landed and published; group 1 one barrier behind
+    if (GN) gn_load(s_begin);
     issue_halo(s_begin, 0);
     issue_b();
     issue_b();
     issue_b();
     wait_keep(2, false);
+    if (GN) gn_apply_slab(0);
     __builtin_amdgcn_s_barrier();
     if (grp1) __builtin_amdgcn_s_barrier();
 
@@ -1323,7 +1368,11 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
 #pragma unroll
         for (int t = 0; t < 9; ++t, ++k) {
             // ------------------------------------------------ read phase (the partner wave of this SIMD is in its MFMA phase)
-            if (t == 0 && s + 1 < s_end) issue_halo(s + 1, hb ^ 1);    // the other buffer was last read in slab s-1: free for everyone
+            if (t == 0 && s + 1 < s_end) {
+                if (GN) gn_load(s + 1);
+                issue_halo(s + 1, hb ^ 1);                             // the other buffer was last read in slab s-1: free for everyone
+            }
+            if (GN && t == 3 && s + 1 < s_end) gn_apply_slab(hb ^ 1);   // my table load and halo pieces of slab s+1 landed at tap 2's wait
             if (k + 3 < nk) issue_b();
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = as_half8(ld16(rdB + j * 1024));
@@ -1349,13 +1398,20 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if (GN)   // in-place form pinned in asm: with the fused-GroupNorm code around, hipcc otherwise renames the accumulators
+                              // between the unrolled taps (D != C) and spills them inside this phase
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fb[j]), "v"(fa[i]));
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
         }
     }
     if (!grp1) __builtin_amdgcn_s_barrier();                            // group 0 waits out group 1's last MFMA phase
+    if (GN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last ones retire before VALU reads the accumulators
     v5_finish(p, acc, smem5, nullptr, nullptr, 0, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
 }
 
@@ -1458,6 +1514,37 @@ extern "C" void ld_debug_gemm_v5_dbg(int bits) { g_v5_dbg = bits; }   // 1: no D
 bool gemm_ln_fold_available() { return true; }
 const char* gemm_last_kernel_name() { return t_last_kernel; }
 
+// does this convolution run on the halo-tile kernel (v6), and with which split over K?
+static bool v6_plan(const GemmParams& p, int* sk_out) {
+    if (!(p.conv && p.ksize == 3 && p.stride == 1 && (p.pad < 0 || p.pad == 1) && p.Hv == p.Hs && p.Wv == p.Ws && p.Ho == p.Hs && p.Wo == p.Ws &&
+          (p.Wo == 16 || p.Wo == 32 || p.Wo == 64 || p.Wo == 128) && (p.Ho * p.Wo) % V5_BM == 0 && p.C1 % 32 == 0 && p.C2 % 32 == 0 &&
+          p.N % V5_BN == 0 && p.bm == 0 && p.bn == 0 && p.splitk == 0 && p.batch == 1 && p.act != 2 && p.M % V5_BM == 0))
+        return false;
+#ifdef LD_AB_BUILD
+    if (g_no_v5 & 2) return false;
+#endif
+    const long long t6 = (long long)(p.M / V5_BM) * (p.N / V5_BN);
+    const int NS = (p.C1 + p.C2) / 32;
+    int sk6 = 1;
+    if (t6 < 192 && p.partial != nullptr && p.K >= 5120) {
+        sk6 = (int)((256 + t6 - 1) / t6);
+        const int cap = p.K / 2560;
+        if (sk6 > cap) sk6 = cap;
+        if (sk6 > NS) sk6 = NS;
+        while (sk6 > 1 && (size_t)sk6 * p.M * p.N * sizeof(float) > p.partial_bytes) --sk6;
+    }
+    *sk_out = sk6;
+    return t6 * sk6 >= 192;
+}
+
+bool gemm_conv_fuses_groupnorm(const GemmParams& p) {
+#ifdef LD_AB_BUILD
+    if (g_no_v5 & 4) return false;   // A/B: keep the two-pass GroupNorm in front of the halo kernel
+#endif
+    int sk = 0;
+    return v6_plan(p, &sk);
+}
+
 int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     GemmParams p = pin;
 #ifdef LD_AB_BUILD
@@ -1484,45 +1571,41 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
 
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     // ---- v6 (halo-tile 3x3 convolution on the v5 skeleton): stride-1 convs whose tiles are whole image rows and fill the chip
-    if (p.conv && p.ksize == 3 && p.stride == 1 && (p.pad < 0 || p.pad == 1) && p.Hv == p.Hs && p.Wv == p.Ws && p.Ho == p.Hs && p.Wo == p.Ws &&
-        (p.Wo == 16 || p.Wo == 32 || p.Wo == 64 || p.Wo == 128) && (p.Ho * p.Wo) % V5_BM == 0 && p.C1 % 32 == 0 && p.C2 % 32 == 0 &&
-        p.N % V5_BN == 0 && p.bm == 0 && p.bn == 0 && p.splitk == 0 && p.batch == 1 && p.act != 2
-#ifdef LD_AB_BUILD
-        && !(g_no_v5 & 2)
-#endif
-    ) {
+    int sk6 = 0;
+    if (v6_plan(p, &sk6)) {
         const long long t6 = (long long)(p.M / V5_BM) * (p.N / V5_BN);
-        const int NS = (p.C1 + p.C2) / 32;
-        int sk6 = 1;
-        if (t6 < 192 && p.partial != nullptr && p.K >= 5120) {
-            sk6 = (int)((256 + t6 - 1) / t6);
-            const int cap = p.K / 2560;
-            if (sk6 > cap) sk6 = cap;
-            if (sk6 > NS) sk6 = NS;
-            while (sk6 > 1 && (size_t)sk6 * p.M * p.N * sizeof(float) > p.partial_bytes) --sk6;
-        }
-        if (t6 * sk6 >= 192) {
-            p.splitk = sk6;
-            p.pad = 1;
-            p.n_valid = p.N;
-            dim3 grid((unsigned)(t6 * sk6), 1, 1);
+        p.splitk = sk6;
+        p.pad = 1;
+        p.n_valid = p.N;
+        dim3 grid((unsigned)(t6 * sk6), 1, 1);
+        if (p.gn_scale != nullptr) {
+            if (p.gn_shift == nullptr) return LD_ERR_ARG;
+            t_last_kernel = "conv6_kernel<256,320,halo+groupnorm>";
+            switch (p.Wo) {
+                case 16: hipLaunchKernelGGL((conv6_kernel<16, true>), grid, dim3(512), 0, stream, p); break;
+                case 32: hipLaunchKernelGGL((conv6_kernel<32, true>), grid, dim3(512), 0, stream, p); break;
+                case 64: hipLaunchKernelGGL((conv6_kernel<64, true>), grid, dim3(512), 0, stream, p); break;
+                default: hipLaunchKernelGGL((conv6_kernel<128, true>), grid, dim3(512), 0, stream, p); break;
+            }
+        } else {
             t_last_kernel = "conv6_kernel<256,320,halo>";
             switch (p.Wo) {
-                case 16: hipLaunchKernelGGL((conv6_kernel<16>), grid, dim3(512), 0, stream, p); break;
-                case 32: hipLaunchKernelGGL((conv6_kernel<32>), grid, dim3(512), 0, stream, p); break;
-                case 64: hipLaunchKernelGGL((conv6_kernel<64>), grid, dim3(512), 0, stream, p); break;
-                default: hipLaunchKernelGGL((conv6_kernel<128>), grid, dim3(512), 0, stream, p); break;
+                case 16: hipLaunchKernelGGL((conv6_kernel<16, false>), grid, dim3(512), 0, stream, p); break;
+                case 32: hipLaunchKernelGGL((conv6_kernel<32, false>), grid, dim3(512), 0, stream, p); break;
+                case 64: hipLaunchKernelGGL((conv6_kernel<64, false>), grid, dim3(512), 0, stream, p); break;
+                default: hipLaunchKernelGGL((conv6_kernel<128, false>), grid, dim3(512), 0, stream, p); break;
             }
-            if (sk6 > 1) {
-                const long long total = (long long)p.M * (p.N / 8);
-                int blocks = (int)((total + 255) / 256);
-                if (blocks > 2048) blocks = 2048;
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, 160);
-                t_last_kernel = intern_name(std::string(t_last_kernel) + "+splitk_reduce_kernel");
-            }
-            return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
         }
+        if (sk6 > 1) {
+            const long long total = (long long)p.M * (p.N / 8);
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, 160);
+            t_last_kernel = intern_name(std::string(t_last_kernel) + "+splitk_reduce_kernel");
+        }
+        return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
     }
+    if (p.gn_scale != nullptr) return LD_ERR_ARG;   // only the halo kernel applies a fused GroupNorm (ask gemm_conv_fuses_groupnorm first)
     // ---- v5 (256 x 320 tile, 8 waves, staggered wave groups): whenever its tiles (x an optional split over K) fill the chip
     {
         // measured per shape against v3 (tools/gemm5_ab.py, profiles/README.md): +9..23 % on the K >= 2880 convs, +4..12 % at K = 1280,

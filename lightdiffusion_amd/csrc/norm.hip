@@ -136,6 +136,43 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
     }
 }
 
+// GroupNorm statistics only, finished into per-(image, channel) scale / shift for a consumer that applies them itself (the halo
+// convolution, gemm.h gn_scale / gn_shift): same reduction order and the same  sc = rstd * gamma,  sh = beta - mean * sc  as
+// gn_apply_kernel, so the fused path reproduces the two-pass one bit for bit.  One block per (image, slab of 8 groups).
+__global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(const GnArgs a, float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float mean[8], rstd[8];
+    const int C = a.C1 + a.C2, cpg = C / 32, CS = C / GN_SLABS;
+    const int n = blockIdx.x, slab = blockIdx.y, tid = threadIdx.x;
+    {
+        const int g = tid >> 5, sub = tid & 31;
+        float s = 0.f, ss = 0.f;
+        const float* pp = a.partial + ((long long)n * a.P * 32 + slab * 8 + g) * 2;
+        for (int i = sub; i < a.P; i += 32) {
+            s += pp[(long long)i * 64];
+            ss += pp[(long long)i * 64 + 1];
+        }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            ss += __shfl_xor(ss, o, 64);
+        }
+        if (sub == 0) {
+            const float cnt = (float)cpg * (float)a.HW;
+            const float mu = s / cnt;
+            const float var = fmaxf(ss / cnt - mu * mu, 0.f);
+            mean[g] = mu;
+            rstd[g] = rsqrtf(var + a.eps);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < CS; c += GN_THREADS) {
+        const int g = c / cpg, cg = slab * CS + c;
+        const float sc = rstd[g] * (float)a.gamma[cg];
+        scale[(long long)n * C + cg] = sc;
+        shift[(long long)n * C + cg] = (float)a.beta[cg] - mean[g] * sc;
+    }
+}
+
 // LayerNorm over the last dim: one wave per row, row held in registers (C <= 64 lanes * 4 chunks * 8 = 2048).
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ gamma,
                                                          const half_t* __restrict__ beta, half_t* __restrict__ y,
@@ -242,6 +279,21 @@ int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_i
     dim3 grid(a.P, n_img, GN_SLABS);
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, stream, a);
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int groupnorm_scale_shift_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, const half_t* gamma, const half_t* beta,
+                                 float eps, float* partial, float* scale, float* shift, hipStream_t stream) {
+    const int C = C1 + C2;
+    if (x1 == nullptr || partial == nullptr || gamma == nullptr || beta == nullptr || scale == nullptr || shift == nullptr) return LD_ERR_ARG;
+    if (C % 32 || C1 % 8 || C2 % 8 || C > 8192 || C1 <= 0 || (C2 > 0 && x2 == nullptr)) return LD_ERR_SHAPE;
+    GnArgs a;
+    a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.HW = HW;
+    a.P = gn_num_chunks(n_img, HW);
+    a.ppb = (HW + a.P - 1) / a.P;
+    a.partial = partial; a.gamma = gamma; a.beta = beta; a.y = nullptr; a.eps = eps; a.silu = 0;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.P, n_img, GN_SLABS), dim3(GN_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img, GN_SLABS), dim3(GN_THREADS), 0, stream, a, scale, shift);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
 

@@ -213,6 +213,38 @@ struct Exec {
         t_end("gn_stats_kernel+gn_apply_kernel");
         arena->release(m);
     }
+    // GroupNorm(32) + SiLU feeding a 3x3 convolution.  When the convolution runs on the halo-tile kernel the normalisation is fused
+    // into its A operand: only the statistics pass + a tiny finalize run here (scale / shift per image and channel), the conv reads the
+    // RAW tensor(s) — no normalised copy is written or read back.  Otherwise: the two-pass GroupNorm into `g` (caller-provided), then the conv.
+    // `p`: the convolution with A / A2 = the RAW sources; returns through p.C as usual.
+    void gn_silu_conv(GemmParams p, int n_img, int HW, const half_t* gamma, const half_t* beta, float eps, half_t* g) {
+        p.partial = splitk_ws;
+        p.partial_bytes = splitk_bytes;
+        if (gemm_conv_fuses_groupnorm(p)) {
+            const int C = p.C1 + p.C2;
+            const size_t m = arena->mark();
+            float* ws = reinterpret_cast<float*>(arena->alloc(groupnorm_workspace_bytes(n_img, HW)));
+            float* scale = reinterpret_cast<float*>(arena->alloc((size_t)n_img * C * sizeof(float)));
+            float* shift = reinterpret_cast<float*>(arena->alloc((size_t)n_img * C * sizeof(float)));
+            launches += 2;
+            t_begin(KC_GNORM, 0.0, 2, "gn_stats", n_img, HW, C, 1);
+            if (!dry && status == LD_OK)
+                note(groupnorm_scale_shift_launch(p.A, p.C1, p.A2, p.C2, n_img, HW, gamma, beta, eps, ws, scale, shift, stream));
+            t_end("gn_stats_kernel+gn_finalize_kernel");
+            p.gn_scale = scale;
+            p.gn_shift = shift;
+            p.gn_silu = 1;
+            gemm(p);
+            arena->release(m);
+            return;
+        }
+        groupnorm(p.A, p.C1, p.A2, p.C2, n_img, HW, gamma, beta, eps, 1, g);
+        p.A = g;
+        p.A2 = nullptr;
+        p.C1 = p.C1 + p.C2;
+        p.C2 = 0;
+        gemm(p);
+    }
     void layernorm(const half_t* x, const half_t* g, const half_t* b, half_t* y, int rows, int C) {
         launches += 1;
         t_begin(KC_LNORM, 0.0, 1, "layernorm", rows, C);

@@ -294,20 +294,36 @@ struct Run {
         const size_t M = (size_t)n * H * W;
         half_t* out = ar.halfs(M * r.cout);
         const size_t mk = ar.mark();
+        // in_layers: GroupNorm + SiLU + conv3x3 (+ the time-embedding row vector); out_layers: GroupNorm + SiLU + conv3x3 (+ skip).
+        // Each GroupNorm is fused into its convolution's A operand where that convolution runs on the halo-tile kernel
+        // (Exec::gn_silu_conv); g1 / g2 are only written on the two-pass route.
+        auto conv_params = [&](const half_t* a1, int c1, const half_t* a2, int c2, int wslot, int bslot, const half_t* rowvec, int ldrv, const half_t* R,
+                               half_t* dst) {
+            GemmParams p;
+            p.conv = 1; p.ksize = 3;
+            p.A = a1; p.A2 = a2; p.C1 = c1; p.C2 = c2;
+            p.Hs = H; p.Ws = W; p.Hv = H; p.Wv = W; p.Ho = H; p.Wo = W; p.stride = 1;
+            p.W = P(wslot); p.ldw = 9 * (c1 + c2);
+            p.M = n * H * W; p.N = r.cout; p.K = 9 * (c1 + c2);
+            p.bias_n = P(bslot);
+            p.rowvec = rowvec; p.rows_per_vec = H * W; p.ldrv = ldrv;
+            p.R = R; p.ldr = r.cout;
+            p.C = dst; p.ldc = r.cout;
+            return p;
+        };
         half_t* g1 = ar.halfs(M * r.cin);
-        ex.groupnorm(x1, C1, x2, C2, n, H * W, P(r.gn1_g), P(r.gn1_b), 1e-5f, 1, g1);
         half_t* h1 = ar.halfs(M * r.cout);
-        conv3(g1, r.cin, nullptr, 0, H, W, H, W, 1, r.c1_w, r.c1_b, r.cout, emb_all + r.emb_off, u->emb_total, nullptr, h1, nullptr, nullptr);
+        ex.gn_silu_conv(conv_params(x1, C1, x2, C2, r.c1_w, r.c1_b, emb_all + r.emb_off, u->emb_total, nullptr, h1), n, H * W, P(r.gn1_g), P(r.gn1_b),
+                        1e-5f, g1);
         half_t* g2 = g1;   // g1 is dead once conv1 has consumed it (stream order); reuse when it is large enough
         if (r.cout > r.cin) g2 = ar.halfs(M * r.cout);
-        ex.groupnorm(h1, r.cout, nullptr, 0, n, H * W, P(r.gn2_g), P(r.gn2_b), 1e-5f, 1, g2);
         const half_t* skip = x1;
         if (r.sk_w >= 0) {
             half_t* sk = ar.halfs(M * r.cout);
             conv3(x1, C1, x2, C2, H, W, H, W, 1, r.sk_w, r.sk_b, r.cout, nullptr, 0, nullptr, sk, nullptr, nullptr, 1);
             skip = sk;
         }
-        conv3(g2, r.cout, nullptr, 0, H, W, H, W, 1, r.c2_w, r.c2_b, r.cout, nullptr, 0, skip, out, nullptr, nullptr);
+        ex.gn_silu_conv(conv_params(h1, r.cout, nullptr, 0, r.c2_w, r.c2_b, nullptr, 0, skip, out), n, H * W, P(r.gn2_g), P(r.gn2_b), 1e-5f, g2);
         ar.release(mk);
         return {out, r.cout, H, W};
     }

@@ -101,6 +101,21 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]
     return y
 
 
+def group_norm_silu_conv2d(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, w_packed: torch.Tensor,
+                           bias: Optional[torch.Tensor], x2: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None,
+                           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv3x3(SiLU(GroupNorm32(cat(x, x2)))) + rowvec + residual on NHWC fp16 — ResBlock1.in_layers / out_layers (LD.py:5224-5262)
+    as ONE operator: on the halo-tile convolution kernel the normalisation happens inside the conv's A operand."""
+    n, h, w, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    cout = w_packed.shape[0]
+    y = torch.empty(n, h, w, cout, dtype=torch.float16, device=x.device)
+    ws = _ws(lib().ld_op_groupnorm_conv_ws_bytes(c1, c2, n, h, w, cout), x.device)
+    check(lib().ld_op_groupnorm_conv(_p(x), c1, _p(x2), c2, n, h, w, _p(gamma), _p(beta), eps, _p(w_packed), _p(bias), _p(rowvec), _p(residual),
+                                     _p(y), cout, _p(ws), ws.numel(), _stream()), "ld_op_groupnorm_conv")
+    return y
+
+
 def group_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, silu: bool = False,
                x2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GroupNorm(32) (+SiLU) over the channel concat of NHWC x and x2, written as one contiguous NHWC tensor."""

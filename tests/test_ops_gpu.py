@@ -311,3 +311,36 @@ def test_linear_ln_big_tiles(ops):
     assert rel_l2(t.float().cpu(), t_ref.cpu()) < TOL
     y_ref = F.linear(F.layer_norm(t.float(), (C,), gamma.float().to(DEV), beta.float().to(DEV), 1e-5), w.float().to(DEV), b.float().to(DEV))
     assert rel_l2(y.float().cpu(), y_ref.cpu()) < 3e-3
+
+
+@pytest.mark.parametrize("n,h,w,c1,c2,cout,rv,res", [
+    (16, 64, 64, 320, 0, 320, True, False),      # fused into the halo kernel (W = 64), the level-0 ResBlock in_layers
+    (16, 64, 64, 640, 320, 320, True, True),     # fused, two sources: groups of 30 channels straddle the 8-channel chunks AND the source boundary
+    (64, 16, 16, 1280, 0, 1280, False, True),    # fused, W = 16
+    (4, 128, 128, 320, 0, 320, False, False),    # fused, W = 128 (tables live inside the halo buffer)
+    (16, 32, 32, 640, 0, 640, True, True),       # fused, W = 32, split over K
+    (2, 12, 10, 64, 64, 128, True, True)])       # not eligible: two-pass GroupNorm + plain conv through the same entry point
+def test_groupnorm_silu_conv(ops, n, h, w, c1, c2, cout, rv, res):
+    x1 = r16((n, c1, h, w), 101, 2.0) + 0.5
+    x2 = (r16((n, c2, h, w), 102) - 1.0) if c2 else None
+    cin = c1 + c2
+    ga, be = (1 + 0.1 * r16((cin,), 103).float()).half(), r16((cin,), 104, 0.1)
+    wt, b = r16((cout, cin, 3, 3), 105, 1 / math.sqrt(9 * cin)), r16((cout,), 106, 0.1)
+    xin = x1.float().to(DEV) if x2 is None else torch.cat([x1.float(), x2.float()], 1).to(DEV)
+    g = F.silu(F.group_norm(xin, 32, ga.float().to(DEV), be.float().to(DEV), 1e-5))
+    ref = F.conv2d(g, wt.float().to(DEV), b.float().to(DEV), padding=1)
+    rowvec = r16((n, cout), 107) if rv else None
+    if rv:
+        ref = ref + rowvec.float().to(DEV)[:, :, None, None]
+    r = r16(tuple(ref.shape), 108) if res else None
+    if res:
+        ref = ref + r.float().to(DEV)
+    y = ops.group_norm_silu_conv2d(nhwc(x1).to(DEV), ga.to(DEV), be.to(DEV), 1e-5, ops.repack_conv_weight(wt.to(DEV)), b.to(DEV),
+                                   None if x2 is None else nhwc(x2).to(DEV), None if rowvec is None else rowvec.to(DEV),
+                                   None if r is None else nhwc(r).to(DEV))
+    assert rel_l2(nchw(y.float().cpu()), ref.cpu()) < TOL
+    # the fused route must agree with the two-pass route (GroupNorm written out, then the same conv) to fp16 rounding of SiLU's reciprocal
+    g16 = ops.group_norm(nhwc(x1).to(DEV), ga.to(DEV), be.to(DEV), 1e-5, True, None if x2 is None else nhwc(x2).to(DEV))
+    y2 = ops.conv2d(g16, ops.repack_conv_weight(wt.to(DEV)), b.to(DEV), 3, 1, None, None, None if rowvec is None else rowvec.to(DEV),
+                    None if r is None else nhwc(r).to(DEV))
+    assert rel_l2(y.float().cpu(), y2.float().cpu()) < 5e-4

@@ -7,7 +7,7 @@ os.environ.setdefault("LD_MI355X_LIB", os.path.join("lightdiffusion_amd", "libld
 from lightdiffusion_amd import weights as W
 from lightdiffusion_amd._lib import lib
 from lightdiffusion_amd.unet import synthetic_unet
-bits = int(sys.argv[1])
+bits = int(sys.argv[1])          # executor flags (ld_debug_unet_flags); add 256 * n to also set ld_debug_gemm_no_v5(n) for the B arm
 batches = [int(a) for a in sys.argv[2:]] or [8, 1]
 L = lib()
 for B in batches:
@@ -19,7 +19,8 @@ for B in batches:
     out = torch.empty_like(x)
     graphs = {}
     for f in (0, bits):
-        L.ld_debug_unet_flags(f)
+        L.ld_debug_unet_flags(f & 255)
+        L.ld_debug_gemm_no_v5(f >> 8)
         st = torch.cuda.Stream()
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
@@ -30,6 +31,7 @@ for B in batches:
         torch.cuda.synchronize()
         graphs[f] = (gr, u.last_launches)
     L.ld_debug_unet_flags(0)
+    L.ld_debug_gemm_no_v5(0)
     t = {f: [] for f in graphs}
     for _ in range(7):
         for f, (gr, _) in graphs.items():
