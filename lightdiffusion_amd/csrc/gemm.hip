@@ -1541,8 +1541,11 @@ bool gemm_conv_fuses_groupnorm(const GemmParams& p) {
 #ifdef LD_AB_BUILD
     if (g_no_v5 & 4) return false;   // A/B: keep the two-pass GroupNorm in front of the halo kernel
 #endif
+    // Measured (tools/gnconv_ab.py, same process): fused vs two-pass GroupNorm + the same halo conv: +4 % at N = 320 (level 0, one N
+    // tile per M tile), +-0 % at N = 640, -3 % at N = 1280 — every N tile of an M tile normalises the same halo again, so the fusion
+    // only pays where the output is one tile wide.
     int sk = 0;
-    return v6_plan(p, &sk);
+    return p.N == V5_BN && v6_plan(p, &sk);
 }
 
 int gemm_launch(const GemmParams& pin, hipStream_t stream) {

@@ -316,9 +316,10 @@ def test_linear_ln_big_tiles(ops):
 @pytest.mark.parametrize("n,h,w,c1,c2,cout,rv,res", [
     (16, 64, 64, 320, 0, 320, True, False),      # fused into the halo kernel (W = 64), the level-0 ResBlock in_layers
     (16, 64, 64, 640, 320, 320, True, True),     # fused, two sources: groups of 30 channels straddle the 8-channel chunks AND the source boundary
-    (64, 16, 16, 1280, 0, 1280, False, True),    # fused, W = 16
+    (256, 16, 16, 1280, 0, 320, False, True),    # fused, W = 16
     (4, 128, 128, 320, 0, 320, False, False),    # fused, W = 128 (tables live inside the halo buffer)
-    (16, 32, 32, 640, 0, 640, True, True),       # fused, W = 32, split over K
+    (64, 32, 32, 640, 0, 320, True, True),       # fused, W = 32
+    (16, 32, 32, 640, 0, 640, True, True),       # two N tiles: two-pass GroupNorm + the plain halo kernel (split over K)
     (2, 12, 10, 64, 64, 128, True, True)])       # not eligible: two-pass GroupNorm + plain conv through the same entry point
 def test_groupnorm_silu_conv(ops, n, h, w, c1, c2, cout, rv, res):
     x1 = r16((n, c1, h, w), 101, 2.0) + 0.5
