@@ -189,7 +189,8 @@ def main():
         dom = max((k for k in agg if agg[k][1] > 0), key=lambda k: agg[k][0])
         d_ms, d_fl, d_n = agg[dom]
         step_flops = unet.last_flops
-        tr = traffic_db.get(tag, {}).get(dom)
+        tr_d = traffic_db.get(tag, {}).get(dom.split("+")[0])      # PMC passes exist for the headline workload (profiles/README.md)
+        tr = tr_d.get("hbm_bytes_per_launch") if tr_d else None   # FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, rocprofv3 --pmc, profiles/*_pmc.csv
         res = {
             "workload": f"SD1.5 512x512 UNet CFG step, {sampler} / {scheduler}-{sched_steps}, batch {B}/GPU (UNet batch {2 * B}), latent {L}x{L}",
             "steps_per_s": world * K / elapsed, "ms_per_step": 1e3 * elapsed / K, "steps": K,
@@ -202,7 +203,7 @@ def main():
             "kernels_ms_per_forward": {k: [round(v[0], 4), v[2]] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]},
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": d_fl / (d_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_F16 / 1e12,
                          "unit": "TFLOP/s", "frac": (d_fl / (d_ms * 1e-3)) / MFMA_PEAK_F16,
-                         "traffic": tr, "launches": d_n, "avg_launch_us": 1e3 * d_ms / max(d_n, 1), "flops_per_launch": d_fl / max(d_n, 1)},
+                         "traffic": tr, "traffic_detail": tr_d, "launches": d_n, "avg_launch_us": 1e3 * d_ms / max(d_n, 1), "flops_per_launch": d_fl / max(d_n, 1)},
         }
         log(f"{tag}: {K} steps in {elapsed:.3f}s -> {res['steps_per_s']:.2f} steps/s ({res['unet_evals_per_s']:.0f} UNet-evals/s); "
             f"dominant {dom} {res['roofline']['achieved']:.0f} TFLOP/s")
