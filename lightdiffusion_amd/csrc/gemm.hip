@@ -1415,6 +1415,260 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     v5_finish(p, acc, smem5, nullptr, nullptr, 0, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
 }
 
+// =====================================================================================================================
+// v7: short-K row-panel GEMM (K = 320: every projection of the level-0 transformer blocks).  One workgroup owns 256 rows and ALL
+// of N.  Its A panel never touches LDS: each wave loads the MFMA fragments of its 32 rows once (20 x 16 bytes per lane, 80 VGPRs)
+// and keeps them for the whole launch.  W streams through a 2-stage LDS-DMA ring in 80-row tiles (51 KB: the full K of 80 output
+// columns), so per 80-column step a wave issues 100 MFMAs against 7 DMA pieces and 50 fragment reads.
+// The two wave groups (waves 0-3 / 4-7: the two waves of every SIMD) run HALF A STEP APART, as in v5, but here the second phase of
+// a step is its EPILOGUE: while one wave of a SIMD issues the MFMAs of step j the other converts, stages and stores step j-1 (bias,
+// LayerNorm fold, activation / GEGLU, residual, row statistics) — the per-tile prologue + epilogue that costs the 128 x 160 kernel
+// 60 % of its time at K = 320 is hidden behind the matrix pipe, and A is read from HBM exactly once.
+//     group 0:  | MFMA j   | EPI j    | MFMA j+1 | EPI j+1  | ...
+//     group 1:  | (idle)   | MFMA j   | EPI j    | MFMA j+1 | ...           ('|' = s_barrier joining all 8 waves)
+//   step j lives in stage j & 1.  Group 0 issues its share of step j+1 in EPI j, group 1 its share of step j+2 in EPI j (the stage is
+//   free by then for both); every interval ends with vmcnt(0) + lgkmcnt(0), so a step is complete one barrier before its first reader.
+// W rows are 640 bytes; chunk c of row r sits at physical chunk (c & ~7) | ((c & 7) ^ (r & 7)) — conflict-free ds_read_b128 for
+// the 16x16x32 operand (the 640-byte pitch shifts odd rows by half a bank row, which separates the two k-chunks of a lane group).
+// GEGLU: steps alternate value / gate blocks of 80 columns; the value step's result waits as packed fp16 in 20 VGPRs.
+// =====================================================================================================================
+constexpr int V7_BM = 256, V7_K = 320, V7_KS = V7_K / 32, V7_NB = 80;
+constexpr int V7_PIECES = 56, V7_STAGE_BYTES = V7_PIECES * 1024;      // 80 rows x 640 bytes = 50 pieces, padded to 7 per wave
+constexpr int V7_EPI_LD = 84;                                          // halfs per staged row (80 + 4 pad: 168 bytes, ds_write_b64 conflict-free)
+constexpr int V7_EPI_BYTES = 32 * V7_EPI_LD * 2;
+
+template <bool GEGLU>
+__global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
+    constexpr int TM = 2, TN = 5;
+    __shared__ __attribute__((aligned(16))) char smem7[2 * V7_STAGE_BYTES + 8 * V7_EPI_BYTES];
+    static_assert(2 * V7_STAGE_BYTES + 8 * V7_EPI_BYTES <= 163840, "LDS");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool grp1 = wid >= 4;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int m0 = blockIdx.x * V7_BM, mw = m0 + wid * 32;              // this wave's 32 rows
+    const int NS = p.N / V7_NB;                                         // steps (80 W rows each)
+
+    // ---- A fragments: rows mw + 16 i + fr, k = 32 ks + 8 fq .. + 7 (rows past M are clamped; their outputs are never stored)
+    half8 fa[TM][V7_KS];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = mw + i * 16 + fr;
+        const half_t* ar = p.A + (long long)(m < p.M ? m : p.M - 1) * p.lda + fq * 8;
+#pragma unroll
+        for (int ks = 0; ks < V7_KS; ++ks) fa[i][ks] = as_half8(ld16(ar + ks * 32));
+    }
+    // ---- LayerNorm fold (consumer): (mu, rstd) of my rows from the producer's per-part (sum, sum of squares)
+    float ln_mu[TM], ln_rs[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        ln_mu[i] = 0.f;
+        ln_rs[i] = 1.f;
+        if (p.ln_stat != nullptr) {
+            const int m = mw + i * 16 + fr;
+            float s1 = 0.f, s2 = 0.f;
+            if (m < p.M)
+                for (int t = 0; t < p.ln_parts; ++t) {
+                    const float* q = p.ln_stat + ((long long)t * p.ln_rows + m) * 2;
+                    s1 += q[0];
+                    s2 += q[1];
+                }
+            const float mu = s1 * p.ln_inv_c;
+            ln_mu[i] = mu;
+            ln_rs[i] = m < p.M ? rsqrtf(fmaxf(s2 * p.ln_inv_c - mu * mu, 0.f) + p.ln_eps) : 0.f;
+        }
+    }
+    // ---- W loader: piece (wid + 8 i) of a stage, lane l -> LDS byte o = piece * 1024 + 16 l -> row o / 640, physical chunk (o % 640) / 16
+    unsigned w_off[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const int o = (wid + 8 * i) * 1024 + lane * 16;
+        int row = o / 640;
+        const int pc = (o - row * 640) >> 4;
+        const int lc = (pc & ~7) | ((pc & 7) ^ (row & 7));
+        if (row > V7_NB - 1) row = V7_NB - 1;                           // the 6 padding pieces re-read the last row (never read back)
+        w_off[i] = (unsigned)(((long long)row * p.ldw + lc * 8) * 2);
+    }
+    const half_t* w_base = p.W;                                        // wave-uniform: W row block of the next step to issue
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem7);
+    int st_issue = 0;
+    auto issue = [&]() {
+        const unsigned dst = smem_base + (unsigned)(st_issue * V7_STAGE_BYTES) + (unsigned)wid * 1024u;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) glds16s(w_off[i], w_base, dst + (unsigned)(8 * i) * 1024u);
+        w_base += (long long)V7_NB * p.ldw;
+        st_issue ^= 1;
+    };
+    // fragment read base: W row (16 j + fr) of the tile, chunk 4 ks + fq -> physical (c & ~7) | ((c & 7) ^ (fr & 7)); rows are 640 bytes
+    const char* rdB = smem7 + fr * 640;
+    int chunk_lo[2];                                                     // (fq ^ (fr & 7)) and ((4 + fq) ^ (fr & 7)): the low 3 bits for even / odd ks
+    chunk_lo[0] = ((fq ^ (fr & 7)) & 7) << 4;
+    chunk_lo[1] = (((4 + fq) ^ (fr & 7)) & 7) << 4;
+    half_t* Cs = reinterpret_cast<half_t*>(smem7 + 2 * V7_STAGE_BYTES + wid * V7_EPI_BYTES);
+
+    f32x4 acc[TM][TN];
+    unsigned vh[GEGLU ? TM * TN * 2 : 1];                               // GEGLU: the finished value block, packed fp16, waits for its gate block
+
+    // ---- one MFMA phase: this step's 80 W rows x K = 320 against my A fragments
+    auto mfma_step = [&](int stage) {
+        const char* T = rdB + stage * V7_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        half8 fb[2][TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = as_half8(ld16(T + j * 16 * 640 + chunk_lo[0]));
+#pragma unroll
+        for (int ks = 0; ks < V7_KS; ++ks) {
+            if (ks + 1 < V7_KS) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[(ks + 1) & 1][j] = as_half8(ld16(T + j * 16 * 640 + (((ks + 1) >> 1) << 7) + chunk_lo[(ks + 1) & 1]));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[ks & 1][j], fa[i][ks], acc[i][j], 0, 0, 0);
+        }
+    };
+    // ---- one epilogue phase: step j (columns n_out .. n_out + 79 of the output; W / bias rows nb .. nb + 79)
+    auto epilogue = [&](int j) {
+        const int nb = j * V7_NB;                                        // row block of W / bias / wsum
+        // (1) finish in accumulator layout: LayerNorm fold, alpha, bias, activation (GEGLU: value kept / gate applied)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                const int n = nb + jj * 16 + fq * 4;
+                f32x4 v = acc[i][jj];
+                if (p.ln_stat != nullptr) {
+                    const f32x4 ws = *reinterpret_cast<const f32x4*>(p.ln_wsum + n);
+                    v = (v - ln_mu[i] * ws) * ln_rs[i];
+                }
+                v *= p.alpha;
+                if (p.bias_n != nullptr) {
+                    const half4 b = *reinterpret_cast<const half4*>(p.bias_n + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
+                }
+                if (GEGLU) {
+                    if ((j & 1) == 0) {                                  // value block: park it
+                        const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        const uint2 u = __builtin_bit_cast(uint2, h);
+                        vh[(i * TN + jj) * 2] = u.x;
+                        vh[(i * TN + jj) * 2 + 1] = u.y;
+                        continue;
+                    }
+                    uint2 u;
+                    u.x = vh[(i * TN + jj) * 2];
+                    u.y = vh[(i * TN + jj) * 2 + 1];
+                    const half4 a = __builtin_bit_cast(half4, u);
+                    const half4 g = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};      // (the gate is rounded to fp16 like the value, as on the v3 path)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (float)a[r] * gelu_f((float)g[r]);
+                } else if (p.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+                } else if (p.act == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+                }
+                const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<half4*>(Cs + (i * 16 + fr) * V7_EPI_LD + jj * 16 + fq * 4) = h;
+            }
+        if (GEGLU && (j & 1) == 0) return;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: my 32 x 80 tile is staged
+        // (2) chunk layout: residual, 16-byte stores of 160-byte row segments, LN-fold producer statistics
+        const int n_out = GEGLU ? (j >> 1) * V7_NB : nb;
+        uint4 rres[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int q = lane + it * 64;
+            const int row = q / 10, cc = q - row * 10;
+            const int m = mw + row;
+            rres[it] = (m < p.M && p.R != nullptr) ? ld16(p.R + (long long)m * p.ldr + n_out + cc * 8) : zero16();
+        }
+        float s1[5], s2[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int q = lane + it * 64;
+            const int row = q / 10, cc = q - row * 10;
+            const int m = mw + row;
+            s1[it] = s2[it] = 0.f;
+            if (m < p.M) {
+                float v[8], r[8];
+                unpack8(ld16(Cs + row * V7_EPI_LD + cc * 8), v);
+                unpack8(rres[it], r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+                const uint4 packed = pack8(v);
+                st16(p.C + (long long)m * p.ldc + n_out + cc * 8, packed);
+                if (p.stat_out != nullptr) {
+                    float f[8];
+                    unpack8(packed, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s1[it] += f[e];
+                        s2[it] += f[e] * f[e];
+                    }
+                }
+            }
+        }
+        if (p.stat_out != nullptr) {   // chunk partials -> LDS (the tile has been consumed) -> one lane per row sums its 10 chunks in order
+            float* sc = reinterpret_cast<float*>(Cs);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int q = lane + it * 64;
+                sc[q * 2] = s1[it];
+                sc[q * 2 + 1] = s2[it];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < 32 && mw + lane < p.M) {
+                float a = 0.f, b = 0.f;
+                for (int c = 0; c < 10; ++c) {
+                    a += sc[(lane * 10 + c) * 2];
+                    b += sc[(lane * 10 + c) * 2 + 1];
+                }
+                float* o = p.stat_out + ((long long)j * p.M + mw + lane) * 2;
+                o[0] = a;
+                o[1] = b;
+            }
+        }
+    };
+    auto end_interval = [&]() {
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ---- prologue: step 0 (everyone) and group 1's share of step 1 in flight; step 0 landed and published; group 1 one barrier behind
+    issue();
+    if (grp1 && NS > 1) issue();
+    if (grp1 && NS > 1) wait_vmcnt<7>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (grp1) __builtin_amdgcn_s_barrier();
+    for (int j = 0; j < NS; ++j) {
+        __builtin_amdgcn_s_setprio(1);
+        mfma_step(j & 1);
+        __builtin_amdgcn_s_setprio(0);
+        end_interval();
+        // group 0: its share of step j+1 (stage free since group 1's MFMA j-1); group 1: its share of step j+2 (stage free since its own MFMA j)
+        if (!grp1) {
+            if (j + 1 < NS) issue();
+        } else {
+            if (j + 2 < NS) issue();
+        }
+        epilogue(j);
+        end_interval();
+    }
+    if (!grp1) __builtin_amdgcn_s_barrier();                            // group 0 waits out group 1's last epilogue: every wave ran 2 NS + 2 barriers
+}
+
 // split-K second pass: sum the fp32 slabs and run the same epilogue
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, int bn) {
     const int out_n = p.act == 2 ? p.N / 2 : p.N;
@@ -1609,6 +1863,25 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
     }
     if (p.gn_scale != nullptr) return LD_ERR_ARG;   // only the halo kernel applies a fused GroupNorm (ask gemm_conv_fuses_groupnorm first)
+    // ---- v7 (row-panel kernel, A fragments in registers): the K = 320 projections whose 256-row panels fill the chip
+    if (!p.conv && p.K == V7_K && p.batch == 1 && !p.ln_swapped && p.bias_m == nullptr && p.rowvec == nullptr && p.bm == 0 && (p.bn == 0 || p.bn == 160) &&
+        p.splitk == 0 && (p.n_valid <= 0 || p.n_valid >= p.N) && p.N % (p.act == 2 ? 160 : V7_NB) == 0 && (p.M + V7_BM - 1) / V7_BM >= 192 &&
+        (p.act != 2 || (p.bias_n != nullptr && p.stat_out == nullptr))
+#ifdef LD_AB_BUILD
+        && !(g_no_v5 & 8)
+#endif
+    ) {
+        if (p.stat_parts_out != nullptr) *p.stat_parts_out = p.N / V7_NB;
+        dim3 grid((unsigned)((p.M + V7_BM - 1) / V7_BM), 1, 1);
+        if (p.act == 2) {
+            t_last_kernel = "gemm7_kernel<256,K320,geglu>";
+            hipLaunchKernelGGL((gemm7_kernel<true>), grid, dim3(512), 0, stream, p);
+        } else {
+            t_last_kernel = "gemm7_kernel<256,K320,plain>";
+            hipLaunchKernelGGL((gemm7_kernel<false>), grid, dim3(512), 0, stream, p);
+        }
+        return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+    }
     // ---- v5 (256 x 320 tile, 8 waves, staggered wave groups): whenever its tiles (x an optional split over K) fill the chip
     {
         // measured per shape against v3 (tools/gemm5_ab.py, profiles/README.md): +9..23 % on the K >= 2880 convs, +4..12 % at K = 1280,

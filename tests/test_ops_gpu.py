@@ -345,3 +345,59 @@ def test_groupnorm_silu_conv(ops, n, h, w, c1, c2, cout, rv, res):
     y2 = ops.conv2d(g16, ops.repack_conv_weight(wt.to(DEV)), b.to(DEV), 3, 1, None, None, None if rowvec is None else rowvec.to(DEV),
                     None if r is None else nhwc(r).to(DEV))
     assert rel_l2(y.float().cpu(), y2.float().cpu()) < 5e-4
+
+
+# ------------------------------------------------------------------ the row-panel kernel (gemm7_kernel): K = 320, A fragments in registers
+@pytest.mark.parametrize("M,N,bias,res,act", [
+    (65536, 320, True, True, "none"), (65536, 640, False, False, "none"), (50001, 320, True, False, "silu"), (49152, 960, True, True, "quick_gelu"),
+    (65536, 80, True, False, "none")])
+def test_linear_row_panel(ops, M, N, bias, res, act):
+    K = 320
+    x, w = r16((M, K), 111), r16((N, K), 112, 1 / math.sqrt(K))
+    b = r16((N,), 113, 0.1) if bias else None
+    r = r16((M, N), 114) if res else None
+    y = ops.linear(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), None if r is None else r.to(DEV), act=act)
+    ref = F.linear(x.float().to(DEV), w.float().to(DEV), None if b is None else b.float().to(DEV))
+    if act == "silu":
+        ref = F.silu(ref)
+    elif act == "quick_gelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    if r is not None:
+        ref = ref + r.float().to(DEV)
+    assert rel_l2(y.float().cpu(), ref.cpu()) < TOL
+    rows = torch.tensor([0, 1, 31, 32, 255, 256, M // 2 + 3, M - 257, M - 1])
+    ref_cpu = F.linear(x[rows].float(), w.float(), None if b is None else b.float())
+    if act == "silu":
+        ref_cpu = F.silu(ref_cpu)
+    elif act == "quick_gelu":
+        ref_cpu = ref_cpu * torch.sigmoid(1.702 * ref_cpu)
+    if r is not None:
+        ref_cpu = ref_cpu + r[rows].float()
+    assert rel_l2(y[rows].float().cpu(), ref_cpu) < TOL
+
+
+def test_geglu_row_panel(ops):
+    M, C = 65536, 320
+    x, w, b = r16((M, C), 115), r16((8 * C, C), 116, 1 / math.sqrt(C)), r16((8 * C,), 117, 0.1)
+    r = r16((M, 4 * C), 118)
+    y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV), act="geglu")
+    a, g = F.linear(x.float().to(DEV), w.float().to(DEV), b.float().to(DEV)).chunk(2, dim=-1)
+    assert rel_l2(y.float().cpu(), (a * F.gelu(g) + r.float().to(DEV)).cpu()) < TOL
+    rows = torch.tensor([0, 17, 255, 256, M - 1])
+    a, g = F.linear(x[rows].float(), w.float(), b.float()).chunk(2, dim=-1)
+    assert rel_l2(y[rows].float().cpu(), a * F.gelu(g) + r[rows].float()) < TOL
+
+
+def test_linear_ln_row_panel(ops):
+    """LN fold through the row-panel kernel: producer statistics per 80-column step, consumer with (mu, rstd) in registers, at K = C = 320."""
+    M, C, N = 65536, 320, 2560
+    g = torch.Generator().manual_seed(119)
+    x = (torch.randn(M, C, generator=g) * 2.0 + 0.7).half()
+    wp, bp = (torch.randn(C, C, generator=g) / math.sqrt(C)).half(), (0.1 * torch.randn(C, generator=g)).half()
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).half(), (0.1 * torch.randn(C, generator=g)).half()
+    w, b = (torch.randn(N, C, generator=g) / math.sqrt(C)).half(), (0.1 * torch.randn(N, generator=g)).half()
+    t, y = ops.linear_ln(x.to(DEV), wp.to(DEV), bp.to(DEV), gamma.to(DEV), beta.to(DEV), w.to(DEV), b.to(DEV))
+    t_ref = F.linear(x.float().to(DEV), wp.float().to(DEV), bp.float().to(DEV))
+    assert rel_l2(t.float().cpu(), t_ref.cpu()) < TOL
+    y_ref = F.linear(F.layer_norm(t.float(), (C,), gamma.float().to(DEV), beta.float().to(DEV), 1e-5), w.float().to(DEV), b.float().to(DEV))
+    assert rel_l2(y.float().cpu(), y_ref.cpu()) < 3e-3

@@ -59,8 +59,8 @@ cases = [lin(65536, 320, 320, res=True), lin(65536, 320, 320), lin(65536, 640, 3
          lin(16384, 5120, 640, act=2), lin(16384, 1280, 640), lin(4096, 10240, 1280, act=2), lin(8192, 8000, 8192) if False else lin(8192, 8320, 8192),
          conv(16, 64, 320, 320, True), conv(16, 64, 640, 320), conv(16, 64, 960, 320), conv(16, 64, 640, 640), conv(16, 32, 1280, 1280),
          conv(16, 32, 640, 640), conv(16, 16, 1280, 1280)]
-MODE = os.environ.get("AB_MODE", "v5")      # "v5": v3 vs (v5 + v6);  "v6": v5 (no halo kernel) vs v6
-OFF = 3 if MODE == "v5" else 2
+MODE = os.environ.get("AB_MODE", "v5")      # "v5": v3 vs (v5 + v6 + v7);  "v6": v5 (no halo kernel) vs v6;  "v7": without / with the row-panel kernel
+OFF = {"v5": 11, "v6": 2, "v7": 8}[MODE]      # ld_debug_gemm_no_v5 bits: 1 = no v5, 2 = no v6, 4 = no fused GN, 8 = no v7
 print(f"{'shape':34s} {'off us':>9s} {'TF/s':>7s} {'on us':>9s} {'TF/s':>7s}  off/on   ({MODE})")
 for fn, fl, name in cases:
     reps = max(3, min(50, int(2e-3 / (fl / 0.8e15)) + 1))
