@@ -1490,13 +1490,28 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
         if (row > V7_NB - 1) row = V7_NB - 1;                           // the 6 padding pieces re-read the last row (never read back)
         w_off[i] = (unsigned)(((long long)row * p.ldw + lc * 8) * 2);
     }
+    // piece 50 (the first padding piece, issued by wave 2) carries the step's 80 bias halfs (bytes 51200 ..) and 80 LayerNorm-fold row
+    // sums (bytes 51456 ..): the epilogue reads them from LDS instead of waiting on 20 small global loads per step
+    const char* aux_ptr = reinterpret_cast<const char*>(g_zero_row);
+    int aux_step = 0;
+    if (lane < 10 && p.bias_n != nullptr) {
+        aux_ptr = reinterpret_cast<const char*>(p.bias_n + lane * 8);
+        aux_step = V7_NB * 2;
+    } else if (lane >= 16 && lane < 36 && p.ln_wsum != nullptr) {
+        aux_ptr = reinterpret_cast<const char*>(p.ln_wsum + (lane - 16) * 4);
+        aux_step = V7_NB * 4;
+    }
+    const char* p7 = wid == 2 ? aux_ptr : reinterpret_cast<const char*>(p.W) + w_off[6];   // every wave's 7th piece, as a per-lane pointer
+    const long long step7 = wid == 2 ? (long long)aux_step : (long long)V7_NB * p.ldw * 2;
     const half_t* w_base = p.W;                                        // wave-uniform: W row block of the next step to issue
     const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem7);
     int st_issue = 0;
     auto issue = [&]() {
         const unsigned dst = smem_base + (unsigned)(st_issue * V7_STAGE_BYTES) + (unsigned)wid * 1024u;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) glds16s(w_off[i], w_base, dst + (unsigned)(8 * i) * 1024u);
+        for (int i = 0; i < 6; ++i) glds16s(w_off[i], w_base, dst + (unsigned)(8 * i) * 1024u);
+        glds16(reinterpret_cast<const half_t*>(p7), dst + 48u * 1024u);   // per-lane pointer form: wave 2 fetches bias / row sums here
+        p7 += step7;
         w_base += (long long)V7_NB * p.ldw;
         st_issue ^= 1;
     };
@@ -1522,6 +1537,9 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
         for (int j = 0; j < TN; ++j) fb[0][j] = as_half8(ld16(T + j * 16 * 640 + chunk_lo[0]));
 #pragma unroll
         for (int ks = 0; ks < V7_KS; ++ks) {
+#ifdef LD_AB_BUILD
+            if ((p.dbg & 128) && ks > 0) break;
+#endif
             if (ks + 1 < V7_KS) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
@@ -1533,23 +1551,52 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[ks & 1][j], fa[i][ks], acc[i][j], 0, 0, 0);
         }
     };
-    // ---- one epilogue phase: step j (columns n_out .. n_out + 79 of the output; W / bias rows nb .. nb + 79)
-    auto epilogue = [&](int j) {
+    // group 0: its share of step j+1 (stage free since group 1's MFMA j-1); group 1: its share of step j+2 (stage free since its own MFMA j)
+    auto issue_next = [&](int j) {
+        if (!grp1) {
+            if (j + 1 < NS) issue();
+        } else {
+            if (j + 2 < NS) issue();
+        }
+    };
+    const bool full_tile = m0 + V7_BM <= p.M;
+    // ---- one epilogue phase: step j (columns n_out .. n_out + 79 of the output; W / bias rows nb .. nb + 79); returns the number of
+    // store instructions it left as the youngest vector-memory operations of this wave
+    auto epilogue = [&](int j) -> int {
+#ifdef LD_AB_BUILD
+        if (p.dbg & 256) {
+            issue_next(j);
+            return 0;
+        }
+#endif
         const int nb = j * V7_NB;                                        // row block of W / bias / wsum
+        const int n_out = GEGLU ? (j >> 1) * V7_NB : nb;
+        const bool last_half = !GEGLU || (j & 1);
+        uint4 rres[5];                                                   // residual chunks: requested first, consumed in (2)
+        if (last_half) {
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int q = lane + it * 64;
+                const int row = q / 10, cc = q - row * 10;
+                const int m = mw + row;
+                rres[it] = (m < p.M && p.R != nullptr) ? ld16(p.R + (long long)m * p.ldr + n_out + cc * 8) : zero16();
+            }
+        }
+        const char* aux = smem7 + (j & 1) * V7_STAGE_BYTES + 50 * 1024;  // this step's bias (halfs) and, 256 bytes on, LayerNorm-fold row sums (floats)
         // (1) finish in accumulator layout: LayerNorm fold, alpha, bias, activation (GEGLU: value kept / gate applied)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int jj = 0; jj < TN; ++jj) {
-                const int n = nb + jj * 16 + fq * 4;
                 f32x4 v = acc[i][jj];
+                const int nl = jj * 16 + fq * 4;                            // column inside the step
                 if (p.ln_stat != nullptr) {
-                    const f32x4 ws = *reinterpret_cast<const f32x4*>(p.ln_wsum + n);
+                    const f32x4 ws = *reinterpret_cast<const f32x4*>(aux + 256 + nl * 4);
                     v = (v - ln_mu[i] * ws) * ln_rs[i];
                 }
                 v *= p.alpha;
-                if (p.bias_n != nullptr) {
-                    const half4 b = *reinterpret_cast<const half4*>(p.bias_n + n);
+                {
+                    const half4 b = *reinterpret_cast<const half4*>(aux + nl * 2);   // (zeros when there is no bias)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
                 }
@@ -1567,7 +1614,15 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
                     const half4 a = __builtin_bit_cast(half4, u);
                     const half4 g = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};      // (the gate is rounded to fp16 like the value, as on the v3 path)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (float)a[r] * gelu_f((float)g[r]);
+                    for (int r = 0; r < 4; ++r) {
+#ifdef LD_AB_BUILD
+                        if (p.dbg & 512) {
+                            v[r] = (float)a[r] * (float)g[r];
+                            continue;
+                        }
+#endif
+                        v[r] = (float)a[r] * gelu_f((float)g[r]);
+                    }
                 } else if (p.act == 1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
@@ -1578,41 +1633,38 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
                 const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 *reinterpret_cast<half4*>(Cs + (i * 16 + fr) * V7_EPI_LD + jj * 16 + fq * 4) = h;
             }
-        if (GEGLU && (j & 1) == 0) return;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: my 32 x 80 tile is staged
-        // (2) chunk layout: residual, 16-byte stores of 160-byte row segments, LN-fold producer statistics
-        const int n_out = GEGLU ? (j >> 1) * V7_NB : nb;
-        uint4 rres[5];
-#pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int q = lane + it * 64;
-            const int row = q / 10, cc = q - row * 10;
-            const int m = mw + row;
-            rres[it] = (m < p.M && p.R != nullptr) ? ld16(p.R + (long long)m * p.ldr + n_out + cc * 8) : zero16();
+        if (GEGLU && (j & 1) == 0) {
+            issue_next(j);
+            return 0;
         }
+        // Order matters from here on: vector-memory operations retire in order, so the interval's closing wait can leave the (slow to
+        // acknowledge) output stores in flight only if they are the YOUNGEST operations: residual loads retired (with the builtin, which
+        // hipcc's waitcnt pass models — it then adds no wait of its own that would also drain the DMA), then the W pieces of a later
+        // step, then phase (2) and its stores.
+        if (p.R != nullptr) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): residual chunks (and, in order, last step's stores) done
+        issue_next(j);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: my 32 x 80 tile is staged
+        // (2) chunk layout: residual, LN-fold producer statistics, 16-byte stores of 160-byte row segments
+        uint4 packed[5];
         float s1[5], s2[5];
 #pragma unroll
         for (int it = 0; it < 5; ++it) {
             const int q = lane + it * 64;
             const int row = q / 10, cc = q - row * 10;
-            const int m = mw + row;
+            float v[8], r[8];
+            unpack8(ld16(Cs + row * V7_EPI_LD + cc * 8), v);
+            unpack8(rres[it], r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+            packed[it] = pack8(v);
             s1[it] = s2[it] = 0.f;
-            if (m < p.M) {
-                float v[8], r[8];
-                unpack8(ld16(Cs + row * V7_EPI_LD + cc * 8), v);
-                unpack8(rres[it], r);
+            if (p.stat_out != nullptr && mw + row < p.M) {
+                float f[8];
+                unpack8(packed[it], f);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += r[e];
-                const uint4 packed = pack8(v);
-                st16(p.C + (long long)m * p.ldc + n_out + cc * 8, packed);
-                if (p.stat_out != nullptr) {
-                    float f[8];
-                    unpack8(packed, f);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        s1[it] += f[e];
-                        s2[it] += f[e] * f[e];
-                    }
+                for (int e = 0; e < 8; ++e) {
+                    s1[it] += f[e];
+                    s2[it] += f[e] * f[e];
                 }
             }
         }
@@ -1637,9 +1689,29 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
                 o[1] = b;
             }
         }
+#ifdef LD_AB_BUILD
+        if (p.dbg & 1024) return 0;                                      // ablation: no output stores
+#endif
+        if (full_tile) {                                                 // exactly 5 store instructions: the closing wait leaves them in flight
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int q = lane + it * 64;
+                const int row = q / 10, cc = q - row * 10;
+                st16(p.C + (long long)(mw + row) * p.ldc + n_out + cc * 8, packed[it]);
+            }
+            return 5;
+        }
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int q = lane + it * 64;
+            const int row = q / 10, cc = q - row * 10;
+            if (mw + row < p.M) st16(p.C + (long long)(mw + row) * p.ldc + n_out + cc * 8, packed[it]);
+        }
+        return 0;
     };
-    auto end_interval = [&]() {
-        wait_vmcnt<0>();
+    auto end_interval = [&](int keep_stores) {
+        if (keep_stores == 5) wait_vmcnt<5>();
+        else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -1652,19 +1724,17 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (grp1) __builtin_amdgcn_s_barrier();
+    int st = 0;
     for (int j = 0; j < NS; ++j) {
-        __builtin_amdgcn_s_setprio(1);
         mfma_step(j & 1);
+        end_interval(st);                                                // my DMA share is older than the last epilogue's stores: those may stay in flight
+        // The epilogue runs at raised priority: on this chip a VALU stream and an MFMA stream of the two waves of a SIMD take the SUM of
+        // their times when the MFMA wave has (equal or higher) priority — it holds the vector issue port while the matrix pipe is busy —
+        // and the MAX when the VALU wave has priority (tools/micro/coexec.hip, profiles/README.md).
+        __builtin_amdgcn_s_setprio(2);
+        st = epilogue(j);
         __builtin_amdgcn_s_setprio(0);
-        end_interval();
-        // group 0: its share of step j+1 (stage free since group 1's MFMA j-1); group 1: its share of step j+2 (stage free since its own MFMA j)
-        if (!grp1) {
-            if (j + 1 < NS) issue();
-        } else {
-            if (j + 2 < NS) issue();
-        }
-        epilogue(j);
-        end_interval();
+        end_interval(st);
     }
     if (!grp1) __builtin_amdgcn_s_barrier();                            // group 0 waits out group 1's last epilogue: every wave ran 2 NS + 2 barriers
 }
@@ -1768,6 +1838,18 @@ extern "C" void ld_debug_gemm_v5_dbg(int bits) { g_v5_dbg = bits; }   // 1: no D
 bool gemm_ln_fold_available() { return true; }
 const char* gemm_last_kernel_name() { return t_last_kernel; }
 
+// Measured (tools/gemm5_ab.py AB_MODE=v7, same process): the row-panel kernel is +14..27 % over the 128 x 160 kernel on the plain K = 320
+// projections (31 vs 36 us at 65536 x 320, 51 vs 64 us at 65536 x 640) but -8 % on the level-0 GEGLU (198 vs 183 us): its gate step's epilogue
+// (40 erf-GELUs + conversions per lane, ~1000 VALU instructions) is four times the length of the MFMA phase it is meant to hide behind.
+// GEGLU therefore stays on the 128 x 160 kernel; the A/B build can force it for experiments.
+static bool v7_geglu_enabled() {
+#ifdef LD_AB_BUILD
+    return (g_no_v5 & 16) != 0;
+#else
+    return false;
+#endif
+}
+
 // does this convolution run on the halo-tile kernel (v6), and with which split over K?
 static bool v6_plan(const GemmParams& p, int* sk_out) {
     if (!(p.conv && p.ksize == 3 && p.stride == 1 && (p.pad < 0 || p.pad == 1) && p.Hv == p.Hs && p.Wv == p.Ws && p.Ho == p.Hs && p.Wo == p.Ws &&
@@ -1866,7 +1948,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     // ---- v7 (row-panel kernel, A fragments in registers): the K = 320 projections whose 256-row panels fill the chip
     if (!p.conv && p.K == V7_K && p.batch == 1 && !p.ln_swapped && p.bias_m == nullptr && p.rowvec == nullptr && p.bm == 0 && (p.bn == 0 || p.bn == 160) &&
         p.splitk == 0 && (p.n_valid <= 0 || p.n_valid >= p.N) && p.N % (p.act == 2 ? 160 : V7_NB) == 0 && (p.M + V7_BM - 1) / V7_BM >= 192 &&
-        (p.act != 2 || (p.bias_n != nullptr && p.stat_out == nullptr))
+        (p.act != 2 || (p.bias_n != nullptr && p.stat_out == nullptr && v7_geglu_enabled()))
 #ifdef LD_AB_BUILD
         && !(g_no_v5 & 8)
 #endif
