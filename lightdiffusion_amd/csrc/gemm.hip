@@ -1919,7 +1919,8 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         dim3 grid((unsigned)(t6 * sk6), 1, 1);
         if (p.gn_scale != nullptr) {
             if (p.gn_shift == nullptr) return LD_ERR_ARG;
-            t_last_kernel = "conv6_kernel<256,320,halo+groupnorm>";
+            t_last_kernel = p.Wo == 16 ? "conv6_kernel<W16,halo+groupnorm>" : p.Wo == 32 ? "conv6_kernel<W32,halo+groupnorm>"
+                          : p.Wo == 64 ? "conv6_kernel<W64,halo+groupnorm>" : "conv6_kernel<W128,halo+groupnorm>";
             switch (p.Wo) {
                 case 16: hipLaunchKernelGGL((conv6_kernel<16, true>), grid, dim3(512), 0, stream, p); break;
                 case 32: hipLaunchKernelGGL((conv6_kernel<32, true>), grid, dim3(512), 0, stream, p); break;
@@ -1927,7 +1928,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
                 default: hipLaunchKernelGGL((conv6_kernel<128, true>), grid, dim3(512), 0, stream, p); break;
             }
         } else {
-            t_last_kernel = "conv6_kernel<256,320,halo>";
+            t_last_kernel = p.Wo == 16 ? "conv6_kernel<W16,halo>" : p.Wo == 32 ? "conv6_kernel<W32,halo>" : p.Wo == 64 ? "conv6_kernel<W64,halo>" : "conv6_kernel<W128,halo>";
             switch (p.Wo) {
                 case 16: hipLaunchKernelGGL((conv6_kernel<16, false>), grid, dim3(512), 0, stream, p); break;
                 case 32: hipLaunchKernelGGL((conv6_kernel<32, false>), grid, dim3(512), 0, stream, p); break;

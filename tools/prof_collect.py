@@ -20,6 +20,12 @@ def short_name(k):
     m = re.match(r"gemm5_kernel<(true|false)>", k)
     if m:
         return f"gemm5_kernel<256,320,{'conv' if m.group(1) == 'true' else 'plain'}>"
+    m = re.match(r"conv6_kernel<(\d+), (true|false)>", k)
+    if m:
+        return f"conv6_kernel<W{m.group(1)},{'halo+groupnorm' if m.group(2) == 'true' else 'halo'}>"
+    m = re.match(r"gemm7_kernel<(true|false)>", k)
+    if m:
+        return f"gemm7_kernel<256,K320,{'geglu' if m.group(1) == 'true' else 'plain'}>"
     m = re.match(r"flash_attn2_kernel<(\d+), (true|false), (\d+), \d+>", k)
     if m:
         return f"flash_attn2_kernel<{m.group(1)},{'masked' if m.group(2) == 'true' else 'plain'},{m.group(3)}>"
@@ -55,7 +61,7 @@ def main():
                 f.write(f'"{k}",{c},{acc[k][c][0] / acc[k][c][1]:.6g},{acc[k][c][1]}\n')
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     db = json.load(open(tp)) if os.path.exists(tp) else {}
-    t = db.setdefault(tag, {})
+    t = db[tag] = {}   # a pass replaces the tag: kernel names change between rounds
     for k in acc:
         e = {}
         if "FETCH_SIZE" in acc[k]:
