@@ -42,11 +42,21 @@ __device__ __forceinline__ void unpack8(uint4 v, float (&f)[8]) {
     for (int i = 0; i < 8; ++i) f[i] = (float)t.e[i];
 }
 
-__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
-    H8 t;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t.e[i] = (half_t)f[i];
-    return t.u;
+// two floats -> packed fp16 pair, round to nearest even: ONE v_cvt_pk_f16_f32 (through the element-wise union hipcc emits two
+// v_cvt_f16_f32 and a v_perm / v_pack per pair)
+__device__ __forceinline__ unsigned pk2h(float a, float b) {
+    const half2v h = {(half_t)a, (half_t)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) { return make_uint4(pk2h(f[0], f[1]), pk2h(f[2], f[3]), pk2h(f[4], f[5]), pk2h(f[6], f[7])); }
+
+// eight fp16 sums, packed (v_pk_add_f16)
+__device__ __forceinline__ uint4 add8h(uint4 a, uint4 b) {
+    H8 x, y;
+    x.u = a;
+    y.u = b;
+    x.h = x.h + y.h;
+    return x.u;
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
@@ -59,6 +69,78 @@ __device__ __forceinline__ float gelu_f(float x) {
     const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     const float erf_abs = 1.0f - poly * __expf(-z * z);
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+// GEGLU products for 8 (value, gate) pairs: ow[k] = fp16x2( a * gelu(g) ) with the erf of gelu_f (Abramowitz-Stegun 7.1.26), written as
+// volatile asm STAGE BY STAGE over 4 register pairs.  Why asm: a wave that shares its SIMD with a partner wave's MFMA stream gets a vector
+// issue slot only when it has an instruction READY — every bubble is taken by an MFMA, which then holds the port for its passes
+// (measured in the row-panel GEMM: 12 clocks per vector instruction with one dependency chain after the other).  hipcc schedules the
+// 40 independent GELUs of a gate step chain by chain whatever the source order (and folds sched_barriers between pure operations), so the
+// interleaving is pinned here: volatile asm statements keep their order.  Packed fp32 where the ISA has it: 12 instructions per product.
+// aw: 4 packed fp16 value pairs, g: the 8 gates (fp32), ow: 4 packed fp16 results.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void geglu8_staged(const unsigned (&aw)[4], const f32x2 (&g)[4], unsigned (&ow)[4]) {
+    const f32x2 kP = {0.3275911f, 0.3275911f}, kL = {1.44269504088896340736f, 1.44269504088896340736f};
+    const f32x2 kA5 = {1.061405429f, 1.061405429f}, kA3 = {1.421413741f, 1.421413741f}, kA2 = {-0.284496736f, -0.284496736f},
+                kA1 = {0.254829592f, 0.254829592f};
+    f32x2 kA4 = {-1.453152027f, -1.453152027f};
+    asm volatile("" : "+v"(kA4));                 // lives in VGPRs: a VOP3P instruction takes one scalar operand
+    const float kC = 0.70710678118654752440f;
+    const unsigned kM = 0x7fffffffu;
+    f32x2 z[4], t[4], e[4], q[4], a[4];
+    asm volatile("s_nop 1");                       // (the inputs may come straight from packed-fp32 producers the asm reads are invisible to)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                  // z = |g| / sqrt(2)
+        asm volatile("v_mul_f32 %0, |%1|, %2" : "=v"(z[k].x) : "v"(g[k].x), "s"(kC));
+        asm volatile("v_mul_f32 %0, |%1|, %2" : "=v"(z[k].y) : "v"(g[k].y), "s"(kC));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel_hi:[1,1,0]" : "=v"(t[k]) : "v"(z[k]), "s"(kP));   // 1 + p z
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_pk_mul_f32 %0, %1, %1 neg_lo:[1,0] neg_hi:[1,0]" : "=v"(e[k]) : "v"(z[k]));         // -z^2
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                  // t = 1 / (1 + p z)
+        asm volatile("v_rcp_f32 %0, %0" : "+v"(t[k].x));
+        asm volatile("v_rcp_f32 %0, %0" : "+v"(t[k].y));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(e[k]) : "s"(kL));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                  // e = exp(-z^2)
+        asm volatile("v_exp_f32 %0, %0" : "+v"(e[k].x));
+        asm volatile("v_exp_f32 %0, %0" : "+v"(e[k].y));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(q[k]) : "v"(t[k]), "s"(kA5), "v"(kA4));           // Horner in t
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(q[k]) : "v"(t[k]), "s"(kA3));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(q[k]) : "v"(t[k]), "s"(kA2));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(q[k]) : "v"(t[k]), "s"(kA1));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(q[k]) : "v"(t[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)                    // erf(|z|) = 1 - poly * e
+        asm volatile("v_pk_fma_f32 %0, %0, %1, 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(q[k]) : "v"(e[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                  // the value halves, to fp32
+        asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(a[k].x) : "v"(aw[k]));
+        asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(a[k].y) : "v"(aw[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                  // copysign(erf, g)
+        asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(q[k].x) : "s"(kM), "v"(g[k].x));
+        asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(q[k].y) : "s"(kM), "v"(g[k].y));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_pk_mul_f32 %0, %1, 0.5 op_sel_hi:[1,0]" : "=v"(t[k]) : "v"(g[k]));                   // g / 2
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %1, %0, %1" : "+v"(q[k]) : "v"(t[k]));                                // gelu = g/2 * erf + g/2
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(q[k]) : "v"(a[k]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ow[k]) : "v"(q[k].x), "v"(q[k].y));
 }
 
 // quick_gelu of the CLIP MLP: a * sigmoid(1.702 a)  (ACTIVATIONS, LD.py:4296-4299)

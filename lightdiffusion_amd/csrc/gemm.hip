@@ -1421,27 +1421,39 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
 // and keeps them for the whole launch.  W streams through a 2-stage LDS-DMA ring in 80-row tiles (51 KB: the full K of 80 output
 // columns), so per 80-column step a wave issues 100 MFMAs against 7 DMA pieces and 50 fragment reads.
 // The two wave groups (waves 0-3 / 4-7: the two waves of every SIMD) run HALF A STEP APART, as in v5, but here the second phase of
-// a step is its EPILOGUE: while one wave of a SIMD issues the MFMAs of step j the other converts, stages and stores step j-1 (bias,
-// LayerNorm fold, activation / GEGLU, residual, row statistics) — the per-tile prologue + epilogue that costs the 128 x 160 kernel
-// 60 % of its time at K = 320 is hidden behind the matrix pipe, and A is read from HBM exactly once.
+// a step is its EPILOGUE: while one wave of a SIMD issues the MFMAs of step j the other finishes and stores step j-1 (bias,
+// LayerNorm fold, GEGLU, residual, row statistics) — the per-tile prologue + epilogue that costs the 128 x 160 kernel 60 % of its
+// time at K = 320 is hidden behind the matrix pipe, and A is read from HBM exactly once.
 //     group 0:  | MFMA j   | EPI j    | MFMA j+1 | EPI j+1  | ...
 //     group 1:  | (idle)   | MFMA j   | EPI j    | MFMA j+1 | ...           ('|' = s_barrier joining all 8 waves)
 //   step j lives in stage j & 1.  Group 0 issues its share of step j+1 in EPI j, group 1 its share of step j+2 in EPI j (the stage is
-//   free by then for both); every interval ends with vmcnt(0) + lgkmcnt(0), so a step is complete one barrier before its first reader.
-// W rows are 640 bytes; chunk c of row r sits at physical chunk (c & ~7) | ((c & 7) ^ (r & 7)) — conflict-free ds_read_b128 for
-// the 16x16x32 operand (the 640-byte pitch shifts odd rows by half a bank row, which separates the two k-chunks of a lane group).
+//   free by then for both); every interval ends with the DMA retired + lgkmcnt(0), so a step is complete one barrier before its first reader.
+// The loop is LDS-bandwidth bound (tools/gemm7_phases.py: with an epilogue that staged its tile through LDS an interval took 4200
+// clocks against 2000 for the fragment reads + DMA writes alone), so the epilogue stays OUT of LDS: the 16 W rows an MFMA tile
+// reads are chosen such that a lane's accumulators of two neighbouring tiles are 8 CONSECUTIVE output columns —
+//     tile jj < 4, MFMA index c  <-  W row 32 (jj >> 1) + 8 (c >> 2) + 4 (jj & 1) + (c & 3);   tile 4: row 64 + (c & 3) + 8 ((c >> 2) & 1) + 4 (c >> 3)
+// — and results leave as 16-byte (tile pairs) / 8-byte (tile 4) stores straight from the accumulator layout: 64 + 64 + 32 bytes per
+// row and step.  W rows are 640 bytes; chunk c of row r sits at physical chunk (c & ~7) | ((c & 7) ^ key(r)), key(r) = (r & 3) | ((r >> 3) & 1) << 2:
+// the 8 rows a lane group reads together (r = x, x+1, x+2, x+3, x+8, .. x+11) have 8 distinct keys -> conflict-free ds_read_b128.
 // GEGLU: steps alternate value / gate blocks of 80 columns; the value step's result waits as packed fp16 in 20 VGPRs.
 // =====================================================================================================================
 constexpr int V7_BM = 256, V7_K = 320, V7_KS = V7_K / 32, V7_NB = 80;
 constexpr int V7_PIECES = 56, V7_STAGE_BYTES = V7_PIECES * 1024;      // 80 rows x 640 bytes = 50 pieces, padded to 7 per wave
-constexpr int V7_EPI_LD = 84;                                          // halfs per staged row (80 + 4 pad: 168 bytes, ds_write_b64 conflict-free)
-constexpr int V7_EPI_BYTES = 32 * V7_EPI_LD * 2;
 
-template <bool GEGLU>
+template <bool GEGLU, bool LN>
 __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
     constexpr int TM = 2, TN = 5;
-    __shared__ __attribute__((aligned(16))) char smem7[2 * V7_STAGE_BYTES + 8 * V7_EPI_BYTES];
-    static_assert(2 * V7_STAGE_BYTES + 8 * V7_EPI_BYTES <= 163840, "LDS");
+    __shared__ __attribute__((aligned(16))) char smem7[2 * V7_STAGE_BYTES];
+#ifdef LD_AB_BUILD
+    // phase timestamps of waves 0 and 4 of one workgroup (tools/gemm7_phases.py): [wave group][step < 32][8 stamps], low 32 bits of s_memtime
+    __shared__ unsigned ts7[2 * 32 * 8];
+    const bool ts_on = (p.dbg & 2048) && blockIdx.x == 9 && (threadIdx.x & 255) == 0;
+    auto stamp = [&](int it_, int k) {
+        if (ts_on && it_ < 32) ts7[((threadIdx.x >> 8) * 32 + it_) * 8 + k] = (unsigned)__builtin_readcyclecounter();
+    };
+#else
+    auto stamp = [&](int, int) {};
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1459,13 +1471,15 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
 #pragma unroll
         for (int ks = 0; ks < V7_KS; ++ks) fa[i][ks] = as_half8(ld16(ar + ks * 32));
     }
-    // ---- LayerNorm fold (consumer): (mu, rstd) of my rows from the producer's per-part (sum, sum of squares)
-    float ln_mu[TM], ln_rs[TM];
+    // ---- LayerNorm fold (consumer): (mu, rstd) of my rows from the producer's per-part (sum, sum of squares).  The whole affine part of
+    // the epilogue,  v = rstd alpha (acc - mu wsum) + bias,  is folded into the accumulators' START value  bias / (rstd alpha) - mu wsum
+    // (set at the head of a step's MFMA phase, which has vector-issue slack), so the epilogue is one multiply by rstd alpha.
+    float rs_a[TM], inv_a[TM], mu_a[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        ln_mu[i] = 0.f;
-        ln_rs[i] = 1.f;
-        if (p.ln_stat != nullptr) {
+        rs_a[i] = p.alpha;
+        mu_a[i] = 0.f;
+        if (LN) {
             const int m = mw + i * 16 + fr;
             float s1 = 0.f, s2 = 0.f;
             if (m < p.M)
@@ -1475,10 +1489,12 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
                     s2 += q[1];
                 }
             const float mu = s1 * p.ln_inv_c;
-            ln_mu[i] = mu;
-            ln_rs[i] = m < p.M ? rsqrtf(fmaxf(s2 * p.ln_inv_c - mu * mu, 0.f) + p.ln_eps) : 0.f;
+            mu_a[i] = mu;
+            rs_a[i] = rsqrtf(fmaxf(s2 * p.ln_inv_c - mu * mu, 0.f) + p.ln_eps) * p.alpha;     // (rows past M: finite garbage, never stored)
         }
+        inv_a[i] = 1.0f / rs_a[i];
     }
+    auto key = [](int r) { return (r & 3) | (((r >> 3) & 1) << 2); };
     // ---- W loader: piece (wid + 8 i) of a stage, lane l -> LDS byte o = piece * 1024 + 16 l -> row o / 640, physical chunk (o % 640) / 16
     unsigned w_off[7];
 #pragma unroll
@@ -1486,12 +1502,12 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
         const int o = (wid + 8 * i) * 1024 + lane * 16;
         int row = o / 640;
         const int pc = (o - row * 640) >> 4;
-        const int lc = (pc & ~7) | ((pc & 7) ^ (row & 7));
+        const int lc = (pc & ~7) | ((pc & 7) ^ key(row));
         if (row > V7_NB - 1) row = V7_NB - 1;                           // the 6 padding pieces re-read the last row (never read back)
         w_off[i] = (unsigned)(((long long)row * p.ldw + lc * 8) * 2);
     }
     // piece 50 (the first padding piece, issued by wave 2) carries the step's 80 bias halfs (bytes 51200 ..) and 80 LayerNorm-fold row
-    // sums (bytes 51456 ..): the epilogue reads them from LDS instead of waiting on 20 small global loads per step
+    // sums (bytes 51456 ..): the epilogue reads them from LDS instead of waiting on small global loads every step
     const char* aux_ptr = reinterpret_cast<const char*>(g_zero_row);
     int aux_step = 0;
     if (lane < 10 && p.bias_n != nullptr) {
@@ -1503,38 +1519,71 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
     }
     const char* p7 = wid == 2 ? aux_ptr : reinterpret_cast<const char*>(p.W) + w_off[6];   // every wave's 7th piece, as a per-lane pointer
     const long long step7 = wid == 2 ? (long long)aux_step : (long long)V7_NB * p.ldw * 2;
-    const half_t* w_base = p.W;                                        // wave-uniform: W row block of the next step to issue
+    // Step order: workgroup b walks the N / 80 steps starting at step j0(b) and wraps, so that the workgroups of an XCD (b, b + 8, ..)
+    // do not all ask its L2 for the same W lines at the same moment.  GEGLU rotates by (value, gate) pairs.
+    const int j0 = GEGLU ? 2 * (int)((blockIdx.x >> 3) % (unsigned)(NS >> 1)) : (int)((blockIdx.x >> 3) % (unsigned)NS);
     const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem7);
-    int st_issue = 0;
+    int n_issued = 0;
     auto issue = [&]() {
-        const unsigned dst = smem_base + (unsigned)(st_issue * V7_STAGE_BYTES) + (unsigned)wid * 1024u;
+        int js = j0 + n_issued;
+        if (js >= NS) js -= NS;
+        const half_t* w_base = p.W + (long long)js * V7_NB * p.ldw;      // wave-uniform: W row block of step js
+        const unsigned dst = smem_base + (unsigned)((n_issued & 1) * V7_STAGE_BYTES) + (unsigned)wid * 1024u;
 #pragma unroll
         for (int i = 0; i < 6; ++i) glds16s(w_off[i], w_base, dst + (unsigned)(8 * i) * 1024u);
-        glds16(reinterpret_cast<const half_t*>(p7), dst + 48u * 1024u);   // per-lane pointer form: wave 2 fetches bias / row sums here
-        p7 += step7;
-        w_base += (long long)V7_NB * p.ldw;
-        st_issue ^= 1;
+        glds16(reinterpret_cast<const half_t*>(p7 + js * step7), dst + 48u * 1024u);   // per-lane pointer form: wave 2 fetches bias / row sums here
+        ++n_issued;
     };
-    // fragment read base: W row (16 j + fr) of the tile, chunk 4 ks + fq -> physical (c & ~7) | ((c & 7) ^ (fr & 7)); rows are 640 bytes
-    const char* rdB = smem7 + fr * 640;
-    int chunk_lo[2];                                                     // (fq ^ (fr & 7)) and ((4 + fq) ^ (fr & 7)): the low 3 bits for even / odd ks
-    chunk_lo[0] = ((fq ^ (fr & 7)) & 7) << 4;
-    chunk_lo[1] = (((4 + fq) ^ (fr & 7)) & 7) << 4;
-    half_t* Cs = reinterpret_cast<half_t*>(smem7 + 2 * V7_STAGE_BYTES + wid * V7_EPI_BYTES);
+    // fragment read bases: the lane that supplies MFMA index fr reads W row  const(jj) + 8 (fr >> 2) + (fr & 3)  (tiles 0..3) or
+    // 64 + (fr & 3) + 8 ((fr >> 2) & 1) + 4 (fr >> 3)  (tile 4); both have key (fr & 3) | ((fr >> 2) & 1) << 2
+    const int kf = (fr & 3) | (((fr >> 2) & 1) << 2);
+    const char* rdP = smem7 + (8 * (fr >> 2) + (fr & 3)) * 640;          // + (32 (jj >> 1) + 4 (jj & 1)) * 640 per tile
+    const char* rdL = smem7 + (64 + (fr & 3) + 8 * ((fr >> 2) & 1) + 4 * (fr >> 3)) * 640;
+    int chunk_lo[2];                                                     // (fq ^ key) and ((4 + fq) ^ key): the low 3 bits for even / odd ks
+    chunk_lo[0] = ((fq ^ kf) & 7) << 4;
+    chunk_lo[1] = (((4 + fq) ^ kf) & 7) << 4;
+    // ---- epilogue addressing (accumulator layout): rows mw + 16 i + fr; tile pair P -> columns 32 P + 8 fq .. + 7, tile 4 -> 64 + c8 .. + 3
+    const int c8 = 64 + 8 * (fq & 1) + 4 * (fq >> 1);
+    int o_c[TM], o_r[TM];                                                // element offsets relative to (row mw, column n_out)
+    bool row_ok[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = mw + 16 * i + fr;
+        row_ok[i] = m < p.M;
+        o_c[i] = (16 * i + fr) * p.ldc;
+        o_r[i] = ((row_ok[i] ? m : p.M - 1) - mw) * p.ldr;
+    }
 
     f32x4 acc[TM][TN];
     unsigned vh[GEGLU ? TM * TN * 2 : 1];                               // GEGLU: the finished value block, packed fp16, waits for its gate block
 
     // ---- one MFMA phase: this step's 80 W rows x K = 320 against my A fragments
     auto mfma_step = [&](int stage) {
-        const char* T = rdB + stage * V7_STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const char* TP = rdP + stage * V7_STAGE_BYTES;
+        const char* TL = rdL + stage * V7_STAGE_BYTES;
+        auto rd = [&](int j, int ks) {
+            const int co = ((ks >> 1) << 7) + chunk_lo[ks & 1];
+            return as_half8(ld16(j < 4 ? TP + (32 * (j >> 1) + 4 * (j & 1)) * 640 + co : TL + co));
+        };
         half8 fb[2][TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[0][j] = as_half8(ld16(T + j * 16 * 640 + chunk_lo[0]));
+        for (int j = 0; j < TN; ++j) fb[0][j] = rd(j, 0);
+        {   // accumulators start at  bias / (rstd alpha) - mu wsum  of my columns (tile jj < 4 -> 32 (jj >> 1) + 8 fq + 4 (jj & 1) .. + 3, tile 4 -> c8 .. + 3)
+            const char* aux = smem7 + stage * V7_STAGE_BYTES + 50 * 1024;   // this step's bias (halfs; zeros when there is none) and, 256 bytes on, LayerNorm-fold row sums (floats)
+            const uint4 b01 = ld16(aux + (8 * fq) * 2), b23 = ld16(aux + (32 + 8 * fq) * 2);
+            const uint2 b4 = *reinterpret_cast<const uint2*>(aux + c8 * 2);
+            const uint2 bt[TN] = {make_uint2(b01.x, b01.y), make_uint2(b01.z, b01.w), make_uint2(b23.x, b23.y), make_uint2(b23.z, b23.w), b4};
+#pragma unroll
+            for (int jj = 0; jj < TN; ++jj) {
+                const half4 bh = __builtin_bit_cast(half4, bt[jj]);
+                f32x4 bf, ws = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bf[r] = (float)bh[r];
+                if (LN) ws = *reinterpret_cast<const f32x4*>(aux + 256 + (jj < 4 ? 32 * (jj >> 1) + 8 * fq + 4 * (jj & 1) : c8) * 4);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][jj] = LN ? bf * inv_a[i] - mu_a[i] * ws : bf * inv_a[i];
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < V7_KS; ++ks) {
 #ifdef LD_AB_BUILD
@@ -1542,8 +1591,7 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
 #endif
             if (ks + 1 < V7_KS) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    fb[(ks + 1) & 1][j] = as_half8(ld16(T + j * 16 * 640 + (((ks + 1) >> 1) << 7) + chunk_lo[(ks + 1) & 1]));
+                for (int j = 0; j < TN; ++j) fb[(ks + 1) & 1][j] = rd(j, ks + 1);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -1561,156 +1609,151 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
     };
     const bool full_tile = m0 + V7_BM <= p.M;
     // ---- one epilogue phase: step j (columns n_out .. n_out + 79 of the output; W / bias rows nb .. nb + 79); returns the number of
-    // store instructions it left as the youngest vector-memory operations of this wave
-    auto epilogue = [&](int j) -> int {
+    // store instructions it left as the youngest vector-memory operations of this wave.  Branch-free, every LDS / global read of a
+    // phase issued as one batch: tile-by-tile read-wait-convert chains measured at twice the MFMA phase they are meant to hide behind.
+    auto epilogue = [&](int it_, int j) -> int {                         // it_: position in this workgroup's walk (stage parity), j: the step
 #ifdef LD_AB_BUILD
         if (p.dbg & 256) {
-            issue_next(j);
+            issue_next(it_);
             return 0;
         }
 #endif
         const int nb = j * V7_NB;                                        // row block of W / bias / wsum
         const int n_out = GEGLU ? (j >> 1) * V7_NB : nb;
-        const bool last_half = !GEGLU || (j & 1);
-        uint4 rres[5];                                                   // residual chunks: requested first, consumed in (2)
-        if (last_half) {
+        // The W pieces of a later step go out FIRST: they then have the whole epilogue to land, and the closing wait of the interval still
+        // finds them older than this epilogue's output stores.  (The stage they overwrite is free: see issue_next; the bias / row-sum
+        // piece this epilogue reads belongs to wave 2's share, which group 0 re-issues one interval later.)
+        issue_next(it_);
+        const bool has_res = !GEGLU && p.R != nullptr;
+        uint4 r16[TM][2];                                                // residual, requested now, added after the activation
+        uint2 r8[TM];
+        if (has_res) {                                                   // (uniform; rows past M read row M - 1, their results are never stored; GEGLU: no residual here)
+            const half_t* Rb = p.R + (long long)mw * p.ldr + n_out;
 #pragma unroll
-            for (int it = 0; it < 5; ++it) {
-                const int q = lane + it * 64;
-                const int row = q / 10, cc = q - row * 10;
-                const int m = mw + row;
-                rres[it] = (m < p.M && p.R != nullptr) ? ld16(p.R + (long long)m * p.ldr + n_out + cc * 8) : zero16();
+            for (int i = 0; i < TM; ++i) {
+                r16[i][0] = ld16(Rb + o_r[i] + 8 * fq);
+                r16[i][1] = ld16(Rb + o_r[i] + 32 + 8 * fq);
+                r8[i] = *reinterpret_cast<const uint2*>(Rb + o_r[i] + c8);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                r16[i][0] = r16[i][1] = zero16();
+                r8[i] = make_uint2(0u, 0u);
             }
         }
-        const char* aux = smem7 + (j & 1) * V7_STAGE_BYTES + 50 * 1024;  // this step's bias (halfs) and, 256 bytes on, LayerNorm-fold row sums (floats)
-        // (1) finish in accumulator layout: LayerNorm fold, alpha, bias, activation (GEGLU: value kept / gate applied)
+        auto affine = [&](int i, int jj) { return acc[i][jj] * rs_a[i]; };   // (bias and the LayerNorm shift went into the accumulators' start value)
+        if (GEGLU && (j & 1) == 0) {                                     // value block: park it (one uniform branch, not one per tile:
+#pragma unroll                                                           //  the gate step below must stay ONE basic block, see there)
+            for (int jj = 0; jj < TN; ++jj)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int jj = 0; jj < TN; ++jj) {
-                f32x4 v = acc[i][jj];
-                const int nl = jj * 16 + fq * 4;                            // column inside the step
-                if (p.ln_stat != nullptr) {
-                    const f32x4 ws = *reinterpret_cast<const f32x4*>(aux + 256 + nl * 4);
-                    v = (v - ln_mu[i] * ws) * ln_rs[i];
+                for (int i = 0; i < TM; ++i) {
+                    const f32x4 v = affine(i, jj);
+                    vh[(i * TN + jj) * 2] = pk2h(v[0], v[1]);
+                    vh[(i * TN + jj) * 2 + 1] = pk2h(v[2], v[3]);
                 }
-                v *= p.alpha;
-                {
-                    const half4 b = *reinterpret_cast<const half4*>(aux + nl * 2);   // (zeros when there is no bias)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)b[r];
-                }
-                if (GEGLU) {
-                    if ((j & 1) == 0) {                                  // value block: park it
-                        const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        const uint2 u = __builtin_bit_cast(uint2, h);
-                        vh[(i * TN + jj) * 2] = u.x;
-                        vh[(i * TN + jj) * 2 + 1] = u.y;
-                        continue;
-                    }
-                    uint2 u;
-                    u.x = vh[(i * TN + jj) * 2];
-                    u.y = vh[(i * TN + jj) * 2 + 1];
-                    const half4 a = __builtin_bit_cast(half4, u);
-                    const half4 g = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};      // (the gate is rounded to fp16 like the value, as on the v3 path)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-#ifdef LD_AB_BUILD
-                        if (p.dbg & 512) {
-                            v[r] = (float)a[r] * (float)g[r];
-                            continue;
-                        }
-#endif
-                        v[r] = (float)a[r] * gelu_f((float)g[r]);
-                    }
-                } else if (p.act == 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-                } else if (p.act == 3) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
-                }
-                const half4 h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                *reinterpret_cast<half4*>(Cs + (i * 16 + fr) * V7_EPI_LD + jj * 16 + fq * 4) = h;
-            }
-        if (GEGLU && (j & 1) == 0) {
-            issue_next(j);
+            stamp(it_, 3);
             return 0;
         }
-        // Order matters from here on: vector-memory operations retire in order, so the interval's closing wait can leave the (slow to
-        // acknowledge) output stores in flight only if they are the YOUNGEST operations: residual loads retired (with the builtin, which
-        // hipcc's waitcnt pass models — it then adds no wait of its own that would also drain the DMA), then the W pieces of a later
-        // step, then phase (2) and its stores.
-        if (p.R != nullptr) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): residual chunks (and, in order, last step's stores) done
-        issue_next(j);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: my 32 x 80 tile is staged
-        // (2) chunk layout: residual, LN-fold producer statistics, 16-byte stores of 160-byte row segments
-        uint4 packed[5];
-        float s1[5], s2[5];
+        uint2 h[TM][TN];
 #pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int q = lane + it * 64;
-            const int row = q / 10, cc = q - row * 10;
-            float v[8], r[8];
-            unpack8(ld16(Cs + row * V7_EPI_LD + cc * 8), v);
-            unpack8(rres[it], r);
+        for (int jj = 0; jj < TN; ++jj) {
+            f32x4 v[TM];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r[e];
-            packed[it] = pack8(v);
-            s1[it] = s2[it] = 0.f;
-            if (p.stat_out != nullptr && mw + row < p.M) {
-                float f[8];
-                unpack8(packed[it], f);
+            for (int i = 0; i < TM; ++i) v[i] = affine(i, jj);
+            if (GEGLU) {                                                 // gate step: out = value * gelu(gate), 8 at a time (common.h: geglu8_staged)
+                const unsigned aw[4] = {vh[jj * 2], vh[jj * 2 + 1], vh[(TN + jj) * 2], vh[(TN + jj) * 2 + 1]};
+                const f32x2 gp[4] = {{v[0][0], v[0][1]}, {v[0][2], v[0][3]}, {v[1][0], v[1][1]}, {v[1][2], v[1][3]}};
+                unsigned ow[4];
+#ifdef LD_AB_BUILD
+                if (p.dbg & 512) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    s1[it] += f[e];
-                    s2[it] += f[e] * f[e];
+                    for (int k = 0; k < 4; ++k) {
+                        const half2v ah = __builtin_bit_cast(half2v, aw[k]);
+                        ow[k] = pk2h((float)ah[0] * gp[k][0], (float)ah[1] * gp[k][1]);
+                    }
+                } else
+#endif
+                    geglu8_staged(aw, gp, ow);
+                h[0][jj] = make_uint2(ow[0], ow[1]);
+                h[1][jj] = make_uint2(ow[2], ow[3]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    h[i][jj].x = pk2h(v[i][0], v[i][1]);
+                    h[i][jj].y = pk2h(v[i][2], v[i][3]);
                 }
             }
         }
-        if (p.stat_out != nullptr) {   // chunk partials -> LDS (the tile has been consumed) -> one lane per row sums its 10 chunks in order
-            float* sc = reinterpret_cast<float*>(Cs);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        stamp(it_, 3);
+        // Vector-memory operations retire in order: the residual is waited for with the builtin (which hipcc's waitcnt pass models: it
+        // then adds no wait of its own), unconditionally (under `if (R)` the model still holds the loads outstanding on the merged path
+        // and parks its own waits further down).  The W pieces issued above are older and retire with it — they have had the whole
+        // finish to land; the output stores below stay the youngest operations, so the interval's closing wait can leave them in flight.
+        if (!GEGLU) __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+        stamp(it_, 4);
+        uint4 o16[TM][2];
+        uint2 o8[TM];
 #pragma unroll
-            for (int it = 0; it < 5; ++it) {
-                const int q = lane + it * 64;
-                sc[q * 2] = s1[it];
-                sc[q * 2 + 1] = s2[it];
+        for (int i = 0; i < TM; ++i) {
+            o16[i][0] = make_uint4(h[i][0].x, h[i][0].y, h[i][1].x, h[i][1].y);
+            o16[i][1] = make_uint4(h[i][2].x, h[i][2].y, h[i][3].x, h[i][3].y);
+            o8[i] = h[i][4];
+            if (has_res) {                                               // packed fp16 adds: the finished tile is fp16 already
+                o16[i][0] = add8h(o16[i][0], r16[i][0]);
+                o16[i][1] = add8h(o16[i][1], r16[i][1]);
+                const uint4 t = add8h(make_uint4(o8[i].x, o8[i].y, 0u, 0u), make_uint4(r8[i].x, r8[i].y, 0u, 0u));
+                o8[i] = make_uint2(t.x, t.y);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane < 32 && mw + lane < p.M) {
-                float a = 0.f, b = 0.f;
-                for (int c = 0; c < 10; ++c) {
-                    a += sc[(lane * 10 + c) * 2];
-                    b += sc[(lane * 10 + c) * 2 + 1];
+        }
+        if (!GEGLU && p.stat_out != nullptr) {   // LN-fold producer: (sum, sum of squares) of the fp16 results per row: 20 columns per lane, then across the 4 lanes of a row
+            const half2v one2 = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned w[10] = {o16[i][0].x, o16[i][0].y, o16[i][0].z, o16[i][0].w, o16[i][1].x, o16[i][1].y, o16[i][1].z, o16[i][1].w, o8[i].x, o8[i].y};
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 10; ++e) {
+                    const half2v hv = __builtin_bit_cast(half2v, w[e]);
+                    s1 = __builtin_amdgcn_fdot2(hv, one2, s1, false);
+                    s2 = __builtin_amdgcn_fdot2(hv, hv, s2, false);
                 }
-                float* o = p.stat_out + ((long long)j * p.M + mw + lane) * 2;
-                o[0] = a;
-                o[1] = b;
+                // lanes fr, fr + 16, fr + 32, fr + 48 hold one row: two swap-and-add steps leave the row total in all four
+                auto a1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+                auto a2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+                s1 = __uint_as_float(a1[0]) + __uint_as_float(a1[1]);
+                s2 = __uint_as_float(a2[0]) + __uint_as_float(a2[1]);
+                a1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s1), __float_as_uint(s1), false, false);
+                a2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+                s1 = __uint_as_float(a1[0]) + __uint_as_float(a1[1]);
+                s2 = __uint_as_float(a2[0]) + __uint_as_float(a2[1]);
+                if (fq == 0 && row_ok[i]) *reinterpret_cast<float2*>(p.stat_out + ((long long)j * p.M + mw + 16 * i + fr) * 2) = make_float2(s1, s2);
             }
         }
 #ifdef LD_AB_BUILD
         if (p.dbg & 1024) return 0;                                      // ablation: no output stores
 #endif
-        if (full_tile) {                                                 // exactly 5 store instructions: the closing wait leaves them in flight
+        half_t* Cb = p.C + (long long)mw * p.ldc + n_out;
+        if (full_tile) {                                                 // exactly 6 store instructions: the closing wait leaves them in flight
 #pragma unroll
-            for (int it = 0; it < 5; ++it) {
-                const int q = lane + it * 64;
-                const int row = q / 10, cc = q - row * 10;
-                st16(p.C + (long long)(mw + row) * p.ldc + n_out + cc * 8, packed[it]);
+            for (int i = 0; i < TM; ++i) {
+                st16(Cb + o_c[i] + 8 * fq, o16[i][0]);
+                st16(Cb + o_c[i] + 32 + 8 * fq, o16[i][1]);
+                *reinterpret_cast<uint2*>(Cb + o_c[i] + c8) = o8[i];
             }
-            return 5;
+            return 6;
         }
 #pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int q = lane + it * 64;
-            const int row = q / 10, cc = q - row * 10;
-            if (mw + row < p.M) st16(p.C + (long long)(mw + row) * p.ldc + n_out + cc * 8, packed[it]);
-        }
+        for (int i = 0; i < TM; ++i)
+            if (row_ok[i]) {
+                st16(Cb + o_c[i] + 8 * fq, o16[i][0]);
+                st16(Cb + o_c[i] + 32 + 8 * fq, o16[i][1]);
+                *reinterpret_cast<uint2*>(Cb + o_c[i] + c8) = o8[i];
+            }
         return 0;
     };
     auto end_interval = [&](int keep_stores) {
-        if (keep_stores == 5) wait_vmcnt<5>();
+        if (keep_stores == 6) wait_vmcnt<6>();
         else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -1725,18 +1768,32 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
     __builtin_amdgcn_s_barrier();
     if (grp1) __builtin_amdgcn_s_barrier();
     int st = 0;
-    for (int j = 0; j < NS; ++j) {
-        mfma_step(j & 1);
+    for (int it_ = 0; it_ < NS; ++it_) {
+        int j = j0 + it_;
+        if (j >= NS) j -= NS;
+        stamp(it_, 0);
+        mfma_step(it_ & 1);
+        stamp(it_, 1);
         end_interval(st);                                                // my DMA share is older than the last epilogue's stores: those may stay in flight
+        stamp(it_, 2);
         // The epilogue runs at raised priority: on this chip a VALU stream and an MFMA stream of the two waves of a SIMD take the SUM of
         // their times when the MFMA wave has (equal or higher) priority — it holds the vector issue port while the matrix pipe is busy —
         // and the MAX when the VALU wave has priority (tools/micro/coexec.hip, profiles/README.md).
         __builtin_amdgcn_s_setprio(2);
-        st = epilogue(j);
+        st = epilogue(it_, j);
         __builtin_amdgcn_s_setprio(0);
+        stamp(it_, 5);
         end_interval(st);
+        stamp(it_, 6);
     }
     if (!grp1) __builtin_amdgcn_s_barrier();                            // group 0 waits out group 1's last epilogue: every wave ran 2 NS + 2 barriers
+#ifdef LD_AB_BUILD
+    if ((p.dbg & 2048) && blockIdx.x == 9 && p.partial != nullptr) {
+        __syncthreads();
+        unsigned* out = reinterpret_cast<unsigned*>(p.partial);
+        for (int q = threadIdx.x; q < 2 * 32 * 8; q += 512) out[q] = ts7[q];
+    }
+#endif
 }
 
 // split-K second pass: sum the fp32 slabs and run the same epilogue
@@ -1838,15 +1895,14 @@ extern "C" void ld_debug_gemm_v5_dbg(int bits) { g_v5_dbg = bits; }   // 1: no D
 bool gemm_ln_fold_available() { return true; }
 const char* gemm_last_kernel_name() { return t_last_kernel; }
 
-// Measured (tools/gemm5_ab.py AB_MODE=v7, same process): the row-panel kernel is +14..27 % over the 128 x 160 kernel on the plain K = 320
-// projections (31 vs 36 us at 65536 x 320, 51 vs 64 us at 65536 x 640) but -8 % on the level-0 GEGLU (198 vs 183 us): its gate step's epilogue
-// (40 erf-GELUs + conversions per lane, ~1000 VALU instructions) is four times the length of the MFMA phase it is meant to hide behind.
-// GEGLU therefore stays on the 128 x 160 kernel; the A/B build can force it for experiments.
+// Measured (tools/gemm5_ab.py AB_MODE=v7, tools/ab_launches.py; profiles/README.md): against the 128 x 160 kernel the row-panel kernel runs the
+// plain K = 320 projections 1.3..1.6x faster (27 vs 36 us at 65536 x 320 with residual, 37 vs 60 us at 65536 x 640) and, since its epilogue
+// left LDS and its GELUs are issued interleaved (common.h: geglu8_staged), the level-0 GEGLU as well.
 static bool v7_geglu_enabled() {
 #ifdef LD_AB_BUILD
-    return (g_no_v5 & 16) != 0;
+    return (g_no_v5 & 16) == 0;      // A/B: bit 16 sends GEGLU back to the 128 x 160 kernel
 #else
-    return false;
+    return true;
 #endif
 }
 
@@ -1862,7 +1918,9 @@ static bool v6_plan(const GemmParams& p, int* sk_out) {
     const long long t6 = (long long)(p.M / V5_BM) * (p.N / V5_BN);
     const int NS = (p.C1 + p.C2) / 32;
     int sk6 = 1;
-    if (t6 < 192 && p.partial != nullptr && p.K >= 5120) {
+    // (split over K only from K = 8640 on: per launch inside the UNet forward (tools/ab_launches.py) the split + reduce pair loses to
+    // the unsplit 128 x 160 kernel at 16384 x 640 x 5760 — 133 vs 124 us — and wins from 8640 on: 171 vs 176, 208 vs 227, 285 vs 329 us)
+    if (t6 < 192 && p.partial != nullptr && p.K >= 8640) {
         sk6 = (int)((256 + t6 - 1) / t6);
         const int cap = p.K / 2560;
         if (sk6 > cap) sk6 = cap;
@@ -1949,63 +2007,55 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     // ---- v7 (row-panel kernel, A fragments in registers): the K = 320 projections whose 256-row panels fill the chip
     if (!p.conv && p.K == V7_K && p.batch == 1 && !p.ln_swapped && p.bias_m == nullptr && p.rowvec == nullptr && p.bm == 0 && (p.bn == 0 || p.bn == 160) &&
         p.splitk == 0 && (p.n_valid <= 0 || p.n_valid >= p.N) && p.N % (p.act == 2 ? 160 : V7_NB) == 0 && (p.M + V7_BM - 1) / V7_BM >= 192 &&
-        (p.act != 2 || (p.bias_n != nullptr && p.stat_out == nullptr && v7_geglu_enabled()))
+        (p.act == 0 || (p.act == 2 && p.bias_n != nullptr && p.stat_out == nullptr && p.R == nullptr && v7_geglu_enabled()))
 #ifdef LD_AB_BUILD
         && !(g_no_v5 & 8)
 #endif
     ) {
         if (p.stat_parts_out != nullptr) *p.stat_parts_out = p.N / V7_NB;
         dim3 grid((unsigned)((p.M + V7_BM - 1) / V7_BM), 1, 1);
+        const bool ln = p.ln_stat != nullptr;
         if (p.act == 2) {
             t_last_kernel = "gemm7_kernel<256,K320,geglu>";
-            hipLaunchKernelGGL((gemm7_kernel<true>), grid, dim3(512), 0, stream, p);
+            if (ln) hipLaunchKernelGGL((gemm7_kernel<true, true>), grid, dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((gemm7_kernel<true, false>), grid, dim3(512), 0, stream, p);
         } else {
             t_last_kernel = "gemm7_kernel<256,K320,plain>";
-            hipLaunchKernelGGL((gemm7_kernel<false>), grid, dim3(512), 0, stream, p);
+            if (ln) hipLaunchKernelGGL((gemm7_kernel<false, true>), grid, dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((gemm7_kernel<false, false>), grid, dim3(512), 0, stream, p);
         }
         return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
     }
     // ---- v5 (256 x 320 tile, 8 waves, staggered wave groups): whenever its tiles (x an optional split over K) fill the chip
     {
-        // measured per shape against v3 (tools/gemm5_ab.py, profiles/README.md): +9..23 % on the K >= 2880 convs, +4..12 % at K = 1280,
-        // even at K = 640, -5..-16 % at K = 320 (one workgroup per CU: nothing overlaps a short tile's prologue and epilogue)
+        // measured per launch inside the UNet forward against v3 (tools/ab_launches.py, profiles/README.md): +5..10 % on the 3x3 convolutions
+        // the halo kernel cannot take and on the K = 1280 GEGLU; plain GEMMs / 1x1 convs with one tile per CU and K <= 1600 LOSE (16384 x
+        // 1280 x 640: 69 vs 50 us, 65536 x 320 x 1600: 108 vs 103 us — nothing overlaps a short tile's prologue and epilogue), and so does
+        // a split over K (4096 x 1280 x 11520: the 128 x 160 kernel's own split is 3 % ahead)
+        const bool conv3 = p.conv && p.ksize == 3;
         const bool shape_ok = !p.ln_swapped && p.bm == 0 && (p.bn == 0 || p.bn == 160) && p.N % V5_BN == 0 && p.K % V5_BK == 0 &&
-                              p.K >= (p.act == 2 ? 1280 : 640) && (p.n_valid == p.N || p.n_valid <= 0 || p.n_valid > p.N) && p.splitk == 0 &&
-                              p.M >= 1024;
+                              p.K >= (p.act == 2 ? 1280 : conv3 ? 640 : 2560) && (p.n_valid == p.N || p.n_valid <= 0 || p.n_valid > p.N) &&
+                              p.splitk == 0 && p.M >= 1024;
 #ifdef LD_AB_BUILD
         if (shape_ok && !(g_no_v5 & 1)) {
 #else
         if (shape_ok) {
 #endif
             const long long t5 = (long long)((p.M + V5_BM - 1) / V5_BM) * (p.N / V5_BN) * p.batch;
-            const bool ln = p.stat_out != nullptr || p.ln_stat != nullptr;
-            int sk5 = 1;
-            if (t5 < 192 && !ln && p.batch == 1 && p.partial != nullptr && p.K >= 5120) {
-                sk5 = (int)((256 + t5 - 1) / t5);
-                const int cap = p.K / 2560;
-                if (sk5 > cap) sk5 = cap;
-                while (sk5 > 1 && (size_t)sk5 * p.M * p.N * sizeof(float) > p.partial_bytes) --sk5;
-            }
-            if (t5 * sk5 >= 192 && !(p.act == 2 && p.stat_out != nullptr)) {
+            if (t5 >= 192 && !(p.act == 2 && p.stat_out != nullptr)) {
                 if (p.stat_parts_out != nullptr) *p.stat_parts_out = 2 * (p.N / V5_BN);
-                p.splitk = sk5;
+                p.splitk = 1;
                 p.bn = 160;
                 if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
-                dim3 grid((unsigned)(((p.M + V5_BM - 1) / V5_BM) * (p.N / V5_BN) * sk5), 1, p.batch);
+                dim3 grid((unsigned)t5, 1, 1);
+                grid.x = (unsigned)(((p.M + V5_BM - 1) / V5_BM) * (p.N / V5_BN));
+                grid.z = (unsigned)p.batch;
                 if (p.conv) {
                     t_last_kernel = "gemm5_kernel<256,320,conv>";
                     hipLaunchKernelGGL((gemm5_kernel<true>), grid, dim3(512), 0, stream, p);
                 } else {
                     t_last_kernel = "gemm5_kernel<256,320,plain>";
                     hipLaunchKernelGGL((gemm5_kernel<false>), grid, dim3(512), 0, stream, p);
-                }
-                if (sk5 > 1) {
-                    const int out_n = p.act == 2 ? p.N / 2 : p.N;
-                    const long long total = (long long)p.M * (out_n / 8);
-                    int blocks = (int)((total + 255) / 256);
-                    if (blocks > 2048) blocks = 2048;
-                    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, 160);
-                    t_last_kernel = intern_name(std::string(t_last_kernel) + "+splitk_reduce_kernel");
                 }
                 return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
             }

@@ -145,7 +145,7 @@ struct Timing {
             per_kernel[j].second.ms += t;
             per_kernel[j].second.flops += i / 2 < kflops.size() ? kflops[i / 2] : 0.0;
             per_kernel[j].second.launches += 1;
-            if (verbose && i / 2 < desc.size()) fprintf(stderr, "[ld_profile] %8.1f us  %s\n", t * 1e3, desc[i / 2].c_str());
+            if (verbose && i / 2 < desc.size()) fprintf(stderr, "[ld_profile] %8.1f us  %s  %s\n", t * 1e3, desc[i / 2].c_str(), kn);
         }
     }
     void destroy() {

@@ -60,15 +60,16 @@ cases = [lin(65536, 320, 320, res=True), lin(65536, 320, 320), lin(65536, 640, 3
          conv(16, 64, 320, 320, True), conv(16, 64, 640, 320), conv(16, 64, 960, 320), conv(16, 64, 640, 640), conv(16, 32, 1280, 1280),
          conv(16, 32, 640, 640), conv(16, 16, 1280, 1280)]
 MODE = os.environ.get("AB_MODE", "v5")      # "v5": v3 vs (v5 + v6 + v7);  "v6": v5 (no halo kernel) vs v6;  "v7": without / with the row-panel kernel
-OFF = {"v5": 11, "v6": 2, "v7": 8}[MODE]      # ld_debug_gemm_no_v5 bits: 1 = no v5, 2 = no v6, 4 = no fused GN, 8 = no v7
+OFF = {"v5": 11 + 16, "v6": 2, "v7": 8 + 16}[MODE]      # ld_debug_gemm_no_v5 bits: 1 = no v5, 2 = no v6, 4 = no fused GN, 8 = no v7, 16 = GEGLU not on v7
+ON = int(os.environ.get("AB_ON", "0"))        # bits of the "on" arm
 print(f"{'shape':34s} {'off us':>9s} {'TF/s':>7s} {'on us':>9s} {'TF/s':>7s}  off/on   ({MODE})")
 for fn, fl, name in cases:
     reps = max(3, min(50, int(2e-3 / (fl / 0.8e15)) + 1))
-    t = {0: [], OFF: []}
+    t = {ON: [], OFF: []}
     for _ in range(3):
-        for off in (OFF, 0):
+        for off in (OFF, ON):
             L.ld_debug_gemm_no_v5(off)
             t[off].append(graph_time(fn, reps))
     L.ld_debug_gemm_no_v5(0)
-    a, b = min(t[OFF]), min(t[0])
+    a, b = min(t[OFF]), min(t[ON])
     print(f"{name:34s} {a * 1e3:9.1f} {fl / a / 1e9:7.0f} {b * 1e3:9.1f} {fl / b / 1e9:7.0f}  {a / b:5.2f}", flush=True)

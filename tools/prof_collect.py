@@ -23,7 +23,7 @@ def short_name(k):
     m = re.match(r"conv6_kernel<(\d+), (true|false)>", k)
     if m:
         return f"conv6_kernel<W{m.group(1)},{'halo+groupnorm' if m.group(2) == 'true' else 'halo'}>"
-    m = re.match(r"gemm7_kernel<(true|false)>", k)
+    m = re.match(r"gemm7_kernel<(true|false)(?:, (?:true|false))?>", k)
     if m:
         return f"gemm7_kernel<256,K320,{'geglu' if m.group(1) == 'true' else 'plain'}>"
     m = re.match(r"flash_attn2_kernel<(\d+), (true|false), (\d+), \d+>", k)
