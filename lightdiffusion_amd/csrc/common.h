@@ -77,9 +77,10 @@ __device__ __forceinline__ float gelu_f(float x) {
 // (measured in the row-panel GEMM: 12 clocks per vector instruction with one dependency chain after the other).  hipcc schedules the
 // 40 independent GELUs of a gate step chain by chain whatever the source order (and folds sched_barriers between pure operations), so the
 // interleaving is pinned here: volatile asm statements keep their order.  Packed fp32 where the ISA has it: 12 instructions per product.
-// aw: 4 packed fp16 value pairs, g: the 8 gates (fp32), ow: 4 packed fp16 results.
+// g: the 8 gates (fp32); values: aw (4 packed fp16 pairs) or af (fp32 pairs); results: ow (4 packed fp16 pairs) or of (fp32 pairs).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void geglu8_staged(const unsigned (&aw)[4], const f32x2 (&g)[4], unsigned (&ow)[4]) {
+template <bool APACKED, bool OPACKED>
+__device__ __forceinline__ void geglu8_staged_t(const unsigned (&aw)[4], const f32x2 (&af)[4], const f32x2 (&g)[4], unsigned (&ow)[4], f32x2 (&of)[4]) {
     const f32x2 kP = {0.3275911f, 0.3275911f}, kL = {1.44269504088896340736f, 1.44269504088896340736f};
     const f32x2 kA5 = {1.061405429f, 1.061405429f}, kA3 = {1.421413741f, 1.421413741f}, kA2 = {-0.284496736f, -0.284496736f},
                 kA1 = {0.254829592f, 0.254829592f};
@@ -123,10 +124,15 @@ __device__ __forceinline__ void geglu8_staged(const unsigned (&aw)[4], const f32
 #pragma unroll
     for (int k = 0; k < 4; ++k)                    // erf(|z|) = 1 - poly * e
         asm volatile("v_pk_fma_f32 %0, %0, %1, 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(q[k]) : "v"(e[k]));
+    if (APACKED) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                  // the value halves, to fp32
-        asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(a[k].x) : "v"(aw[k]));
-        asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(a[k].y) : "v"(aw[k]));
+        for (int k = 0; k < 4; ++k) {              // the value halves, to fp32
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(a[k].x) : "v"(aw[k]));
+            asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(a[k].y) : "v"(aw[k]));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = af[k];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {                  // copysign(erf, g)
@@ -139,8 +145,21 @@ __device__ __forceinline__ void geglu8_staged(const unsigned (&aw)[4], const f32
     for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %1, %0, %1" : "+v"(q[k]) : "v"(t[k]));                                // gelu = g/2 * erf + g/2
 #pragma unroll
     for (int k = 0; k < 4; ++k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(q[k]) : "v"(a[k]));
+    if (OPACKED) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ow[k]) : "v"(q[k].x), "v"(q[k].y));
+        for (int k = 0; k < 4; ++k) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ow[k]) : "v"(q[k].x), "v"(q[k].y));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) of[k] = q[k];
+    }
+}
+__device__ __forceinline__ void geglu8_staged(const unsigned (&aw)[4], const f32x2 (&g)[4], unsigned (&ow)[4]) {
+    f32x2 dummy[4];
+    geglu8_staged_t<true, true>(aw, dummy, g, ow, dummy);
+}
+__device__ __forceinline__ void geglu8_staged_f32(const f32x2 (&af)[4], const f32x2 (&g)[4], f32x2 (&of)[4]) {
+    unsigned dummy[4];
+    geglu8_staged_t<false, false>(dummy, af, g, dummy, of);
 }
 
 // quick_gelu of the CLIP MLP: a * sigmoid(1.702 a)  (ACTIVATIONS, LD.py:4296-4299)

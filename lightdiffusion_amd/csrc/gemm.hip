@@ -27,24 +27,19 @@ constexpr int BK = 64;
 constexpr int NT = 256;
 
 __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int m, int n_out, int n_bias, float (&v)[8]) {
-    // v already holds alpha*acc (and, for GEGLU, the gated product with biases applied)
-    if (p.bias_n != nullptr && p.act != 2) {
-        float b[8];
-        unpack8(ld16(p.bias_n + n_bias), b);
+    // v already holds alpha*acc (and, for GEGLU, the gated product with biases applied).  The operands are requested together, then
+    // consumed: one memory latency instead of one per operand.
+    const bool hb = p.bias_n != nullptr && p.act != 2, hv = p.rowvec != nullptr, hr = p.R != nullptr;
+    const uint4 rb = hb ? ld16(p.bias_n + n_bias) : zero16();
+    const uint4 rv = hv ? ld16(p.rowvec + (long long)(m / p.rows_per_vec) * p.ldrv + n_out) : zero16();
+    const uint4 rr = hr ? ld16(p.R + (long long)z * p.sR + (long long)m * p.ldr + n_out) : zero16();
+    const float bm = p.bias_m != nullptr ? (float)p.bias_m[m] : 0.f;
+    float b[8], e[8], r[8];
+    unpack8(rb, b);
+    unpack8(rv, e);
+    unpack8(rr, r);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += b[j];
-    }
-    if (p.bias_m != nullptr) {
-        const float bm = (float)p.bias_m[m];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += bm;
-    }
-    if (p.rowvec != nullptr) {
-        float b[8];
-        unpack8(ld16(p.rowvec + (long long)(m / p.rows_per_vec) * p.ldrv + n_out), b);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += b[j];
-    }
+    for (int j = 0; j < 8; ++j) v[j] = v[j] + b[j] + bm + e[j];
     if (p.act == 1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
@@ -52,12 +47,8 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int 
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = quick_gelu_f(v[j]);
     }
-    if (p.R != nullptr) {
-        float r[8];
-        unpack8(ld16(p.R + (long long)z * p.sR + (long long)m * p.ldr + n_out), r);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += r[j];
-    }
+    for (int j = 0; j < 8; ++j) v[j] += r[j];
     st16(p.C + (long long)z * p.sC + (long long)m * p.ldc + n_out, pack8(v));
 }
 
@@ -71,6 +62,47 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
     if (p.act == 2) {
         constexpr int CPR = BN / 16;
         constexpr int EIT = (BM * CPR + NT - 1) / NT;
+        if ((BM * CPR) % NT == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {   // interior tile: branch-free, batched reads, interleaved erf-GELUs (common.h)
+            half_t* Cb = p.C + (long long)z * p.sC + (long long)m0 * p.ldc + n0 / 2;
+            const bool hr = p.R != nullptr;
+            const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m0 * p.ldr + n0 / 2 : nullptr;
+            uint4 rba[EIT], rbg[EIT], rres[EIT], ca[EIT], cg[EIT];
+#pragma unroll
+            for (int it = 0; it < EIT; ++it) {
+                const int q = tid + it * NT;
+                const int row = q / CPR, cc = q - row * CPR;
+                rba[it] = ld16(p.bias_n + n0 + cc * 8);
+                rbg[it] = ld16(p.bias_n + n0 + cc * 8 + BN / 2);
+                rres[it] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
+                ca[it] = ld16(Cs + row * CLD + cc * 8);
+                cg[it] = ld16(Cs + row * CLD + BN / 2 + cc * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < EIT; ++it) {
+                const int q = tid + it * NT;
+                const int row = q / CPR, cc = q - row * CPR;
+                float a[8], g[8], ba[8], bg[8], r[8];
+                unpack8(ca[it], a);
+                unpack8(cg[it], g);
+                unpack8(rba[it], ba);
+                unpack8(rbg[it], bg);
+                unpack8(rres[it], r);
+                f32x2 ap[4], gp[4], op[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ap[k] = (f32x2){a[2 * k] + ba[2 * k], a[2 * k + 1] + ba[2 * k + 1]};
+                    gp[k] = (f32x2){g[2 * k] + bg[2 * k], g[2 * k + 1] + bg[2 * k + 1]};
+                }
+                geglu8_staged_f32(ap, gp, op);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[2 * k] = op[k][0] + r[2 * k];
+                    a[2 * k + 1] = op[k][1] + r[2 * k + 1];
+                }
+                st16(Cb + (long long)row * p.ldc + cc * 8, pack8(a));
+            }
+            return;
+        }
         uint4 rba[EIT], rbg[EIT], rres[EIT];
 #pragma unroll
         for (int it = 0; it < EIT; ++it) {
@@ -104,6 +136,67 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
         constexpr int EIT = (BM * CPR + NT - 1) / NT;
         constexpr int GRP = EIT > 5 ? (EIT + 1) / 2 : EIT;   // two passes for the big tiles: bounds the live registers
         const bool hb = p.bias_n != nullptr, hv = p.rowvec != nullptr, hr = p.R != nullptr;
+        // Interior tiles without the rarer operands (bias_m, activation): a branch-free path — no per-chunk predicate, so the LDS and
+        // global reads of a group go out as one batch and are waited for once (the predicated loop below reads, waits and converts
+        // chunk by chunk: measured 12..22 % of the whole launch on the K = 640 / 1280 projections); fp16 pairs converted packed.
+        if ((BM * CPR) % NT == 0 && m0 + BM <= p.M && n0 + BN <= p.N && p.bias_m == nullptr && p.act == 0) {
+            half_t* Cb = p.C + (long long)z * p.sC + (long long)m0 * p.ldc + n0;
+            const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m0 * p.ldr + n0 : nullptr;
+#pragma unroll
+            for (int g0 = 0; g0 < EIT; g0 += GRP) {
+                uint4 rb[GRP], rv[GRP], rres[GRP], cv[GRP];
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) {
+                    if (g0 + k >= EIT) continue;
+                    const int q = tid + (g0 + k) * NT;
+                    const int row = q / CPR, cc = q - row * CPR;
+                    rb[k] = hb ? ld16(p.bias_n + n0 + cc * 8) : zero16();
+                    rv[k] = hv ? ld16(p.rowvec + (long long)((m0 + row) / p.rows_per_vec) * p.ldrv + n0 + cc * 8) : zero16();
+                    rres[k] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
+                    cv[k] = ld16(Cs + row * CLD + cc * 8);
+                }
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) {
+                    if (g0 + k >= EIT) continue;
+                    const int q = tid + (g0 + k) * NT;
+                    const int row = q / CPR, cc = q - row * CPR;
+                    float v[8], b[8], e[8], r[8];
+                    unpack8(cv[k], v);
+                    unpack8(rb[k], b);
+                    unpack8(rv[k], e);
+                    unpack8(rres[k], r);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] + b[j] + 0.f + e[j] + r[j];      // (the same association as the general loop)
+                    const uint4 packed = pack8(v);
+                    st16(Cb + (long long)row * p.ldc + cc * 8, packed);
+                    if (lds_scratch != nullptr) {   // LN-fold producer: row statistics of what was actually stored (the fp16 values)
+                        float f[8];
+                        unpack8(packed, f);
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            s1 += f[j];
+                            s2 += f[j] * f[j];
+                        }
+                        *reinterpret_cast<float2*>(lds_scratch + q * 2) = make_float2(s1, s2);
+                    }
+                }
+            }
+            if (lds_scratch != nullptr) {   // one owner per row sums its CPR chunk partials in chunk order (bitwise reproducible)
+                __syncthreads();
+                if (tid < BM) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+                    for (int c = 0; c < CPR; ++c) {
+                        const float2 t = *reinterpret_cast<const float2*>(lds_scratch + (tid * CPR + c) * 2);
+                        s1 += t.x;
+                        s2 += t.y;
+                    }
+                    *reinterpret_cast<float2*>(p.stat_out + ((long long)(n0 / BN) * p.M + m0 + tid) * 2) = make_float2(s1, s2);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int g0 = 0; g0 < EIT; g0 += GRP) {
             uint4 rb[GRP], rv[GRP], rres[GRP];
@@ -804,6 +897,48 @@ constexpr int V5_SWZ = 0x78;                         // g[x] = (0x78 >> 2x) & 3 
 
 // one 16-row x 160-column strip of a wave's tile: staged fp16 values -> fused epilogue -> 16-byte global stores
 __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* Cs, int z, int m_base, int n_base, int lane, int part) {
+    const bool rows_full = m_base + 16 <= p.M;                          // (wave-uniform) every row of the strip exists: the branch-free paths
+    if (p.act == 2 && rows_full) {   // GEGLU, batched reads + interleaved erf-GELUs (common.h: geglu8_staged)
+        const bool hr = p.R != nullptr;
+        half_t* Cb = p.C + (long long)z * p.sC + (long long)m_base * p.ldc + n_base / 2;
+        const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m_base * p.ldr + n_base / 2 : nullptr;
+        uint4 rba[3], rbg[3], rres[3], ca[3], cg[3];
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int q = lane + it * 64;
+            const int row = q < 160 ? q / 10 : 0, cc = q < 160 ? q - row * 10 : 0;       // (the last pass has 32 live lanes; the others redo chunk 0)
+            rba[it] = ld16(p.bias_n + n_base + cc * 8);
+            rbg[it] = ld16(p.bias_n + n_base + cc * 8 + 80);
+            rres[it] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
+            ca[it] = ld16(Cs + row * V5_EPI_LD + cc * 8);
+            cg[it] = ld16(Cs + row * V5_EPI_LD + 80 + cc * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int q = lane + it * 64;
+            const int row = q < 160 ? q / 10 : 0, cc = q < 160 ? q - row * 10 : 0;
+            float a[8], g[8], ba[8], bg[8], r[8];
+            unpack8(ca[it], a);
+            unpack8(cg[it], g);
+            unpack8(rba[it], ba);
+            unpack8(rbg[it], bg);
+            unpack8(rres[it], r);
+            f32x2 ap[4], gp[4], op[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ap[k] = (f32x2){a[2 * k] + ba[2 * k], a[2 * k + 1] + ba[2 * k + 1]};
+                gp[k] = (f32x2){g[2 * k] + bg[2 * k], g[2 * k + 1] + bg[2 * k + 1]};
+            }
+            geglu8_staged_f32(ap, gp, op);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[2 * k] = op[k][0] + r[2 * k];
+                a[2 * k + 1] = op[k][1] + r[2 * k + 1];
+            }
+            if (q < 160) st16(Cb + (long long)row * p.ldc + cc * 8, pack8(a));
+        }
+        return;
+    }
     if (p.act == 2) {   // GEGLU: the wave's 160 columns are one [80 value | 80 gate] block -> 80 outputs
         uint4 rba[3], rbg[3], rres[3];
 #pragma unroll
@@ -836,6 +971,62 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
         return;
     }
     const bool hb = p.bias_n != nullptr, hv = p.rowvec != nullptr, hr = p.R != nullptr;
+    if (rows_full && p.bias_m == nullptr && p.act == 0) {   // branch-free: the five LDS reads and the global operands go out as one batch
+        half_t* Cb = p.C + (long long)z * p.sC + (long long)m_base * p.ldc + n_base;
+        const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m_base * p.ldr + n_base : nullptr;
+        uint4 rb[5], rv[5], rres[5], cv[5], packed[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int q = lane + it * 64;
+            const int row = q / 20, cc = q - row * 20;
+            rb[it] = hb ? ld16(p.bias_n + n_base + cc * 8) : zero16();
+            rv[it] = hv ? ld16(p.rowvec + (long long)((m_base + row) / p.rows_per_vec) * p.ldrv + n_base + cc * 8) : zero16();
+            rres[it] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
+            cv[it] = ld16(Cs + row * V5_EPI_LD + cc * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            const int q = lane + it * 64;
+            const int row = q / 20, cc = q - row * 20;
+            float v[8], b[8], e[8], r[8];
+            unpack8(cv[it], v);
+            unpack8(rb[it], b);
+            unpack8(rv[it], e);
+            unpack8(rres[it], r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] + b[j] + 0.f + e[j] + r[j];          // (the same association as the general loop)
+            packed[it] = pack8(v);
+            st16(Cb + (long long)row * p.ldc + cc * 8, packed[it]);
+        }
+        if (p.stat_out != nullptr) {   // LN-fold producer: row statistics of the stored fp16 values; chunk partials -> LDS -> one lane per row, in chunk order
+            float* sc = reinterpret_cast<float*>(Cs);
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int q = lane + it * 64;
+                float f[8], s1 = 0.f, s2 = 0.f;
+                unpack8(packed[it], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s1 += f[j];
+                    s2 += f[j] * f[j];
+                }
+                *reinterpret_cast<float2*>(sc + q * 2) = make_float2(s1, s2);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane < 16) {
+                float a = 0.f, b = 0.f;
+#pragma unroll 4
+                for (int c = 0; c < 20; ++c) {
+                    const float2 t = *reinterpret_cast<const float2*>(sc + (lane * 20 + c) * 2);
+                    a += t.x;
+                    b += t.y;
+                }
+                *reinterpret_cast<float2*>(p.stat_out + ((long long)part * p.M + m_base + lane) * 2) = make_float2(a, b);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
     uint4 rb[5], rv[5], rres[5];
 #pragma unroll
     for (int it = 0; it < 5; ++it) {
@@ -1828,9 +2019,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
             const int n = cc * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = 0.f;
-            for (int s = 0; s < p.splitk; ++s) {
-                const float* base = p.partial + ((long long)s * p.M + m) * p.N + n;
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(base), x1 = *reinterpret_cast<const f32x4*>(base + 4);
+            // four slabs per batch of loads, summed in slab order (a split of 16 read one slab after the other is 16 memory latencies in a
+            // row: the reduce launches of the batch-1 step were latency-, not bandwidth-bound)
+            const float* base = p.partial + (long long)m * p.N + n;
+            const long long slab = (long long)p.M * p.N;
+            int s = 0;
+            for (; s + 4 <= p.splitk; s += 4) {
+                f32x4 x0[4], x1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    x0[u] = *reinterpret_cast<const f32x4*>(base + (s + u) * slab);
+                    x1[u] = *reinterpret_cast<const f32x4*>(base + (s + u) * slab + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] += x0[u][j];
+                        v[4 + j] += x1[u][j];
+                    }
+            }
+            for (; s < p.splitk; ++s) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(base + s * slab), x1 = *reinterpret_cast<const f32x4*>(base + s * slab + 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     v[j] += x0[j];
