@@ -136,20 +136,22 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
         constexpr int EIT = (BM * CPR + NT - 1) / NT;
         constexpr int GRP = EIT > 5 ? (EIT + 1) / 2 : EIT;   // two passes for the big tiles: bounds the live registers
         const bool hb = p.bias_n != nullptr, hv = p.rowvec != nullptr, hr = p.R != nullptr;
-        // Interior tiles without the rarer operands (bias_m, activation): a branch-free path — no per-chunk predicate, so the LDS and
+        // Interior tiles without an activation: a branch-free path — no per-chunk predicate, so the LDS and
         // global reads of a group go out as one batch and are waited for once (the predicated loop below reads, waits and converts
         // chunk by chunk: measured 12..22 % of the whole launch on the K = 640 / 1280 projections); fp16 pairs converted packed.
-        if ((BM * CPR) % NT == 0 && m0 + BM <= p.M && n0 + BN <= p.N && p.bias_m == nullptr && p.act == 0) {
+        if ((BM * CPR) % NT == 0 && m0 + BM <= p.M && n0 + BN <= p.N && p.act == 0) {
             half_t* Cb = p.C + (long long)z * p.sC + (long long)m0 * p.ldc + n0;
             const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m0 * p.ldr + n0 : nullptr;
 #pragma unroll
             for (int g0 = 0; g0 < EIT; g0 += GRP) {
                 uint4 rb[GRP], rv[GRP], rres[GRP], cv[GRP];
+                half_t rm[GRP];
 #pragma unroll
                 for (int k = 0; k < GRP; ++k) {
                     if (g0 + k >= EIT) continue;
                     const int q = tid + (g0 + k) * NT;
                     const int row = q / CPR, cc = q - row * CPR;
+                    rm[k] = p.bias_m != nullptr ? p.bias_m[m0 + row] : (half_t)0.f;
                     rb[k] = hb ? ld16(p.bias_n + n0 + cc * 8) : zero16();
                     rv[k] = hv ? ld16(p.rowvec + (long long)((m0 + row) / p.rows_per_vec) * p.ldrv + n0 + cc * 8) : zero16();
                     rres[k] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
@@ -165,8 +167,9 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
                     unpack8(rb[k], b);
                     unpack8(rv[k], e);
                     unpack8(rres[k], r);
+                    const float bm = (float)rm[k];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = v[j] + b[j] + 0.f + e[j] + r[j];      // (the same association as the general loop)
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] + b[j] + bm + e[j] + r[j];       // (the same association as the general loop)
                     const uint4 packed = pack8(v);
                     st16(Cb + (long long)row * p.ldc + cc * 8, packed);
                     if (lds_scratch != nullptr) {   // LN-fold producer: row statistics of what was actually stored (the fp16 values)
@@ -267,6 +270,27 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
 
 // ---- LN fold, consumer side (v3 / v4).  ln_prepare: one thread per LN row of the tile finishes (mu, rstd) from the producer's
 // per-N-tile partials, in part order, into LDS; ln_apply: acc <- rstd * (acc - mu * wsum) in fp32, before the tile is rounded to fp16.
+// (sum, sum of squares) of one row over the producer's parts, in part order; the loads go out four parts at a time (one part after the
+// other is one L2 round trip each — 8 in a row at C = 1280 — in the prologue of every consumer launch)
+__device__ __forceinline__ void ln_sum_parts(const float* q, long long stride, int parts, float& s1, float& s2) {
+    int t = 0;
+    for (; t + 4 <= parts; t += 4) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float2*>(q + (t + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s1 += v[u].x;
+            s2 += v[u].y;
+        }
+    }
+    for (; t < parts; ++t) {
+        const float2 v = *reinterpret_cast<const float2*>(q + t * stride);
+        s1 += v.x;
+        s2 += v.y;
+    }
+}
+
 template <int BM, int BN>
 __device__ __forceinline__ void ln_prepare(const GemmParams& p, float* ln_mu, float* ln_rs, int z, int m0, int n0, int tid) {
     const int cnt = p.ln_swapped ? BN : BM;
@@ -274,13 +298,7 @@ __device__ __forceinline__ void ln_prepare(const GemmParams& p, float* ln_mu, fl
     const bool ok = p.ln_swapped ? (n0 + tid < p.n_valid) : (m0 + tid < p.M);
     const long long row = p.ln_swapped ? (long long)z * p.ln_zrows + n0 + tid : (long long)m0 + tid;
     float s1 = 0.f, s2 = 0.f;
-    if (ok) {
-        for (int t = 0; t < p.ln_parts; ++t) {
-            const float* q = p.ln_stat + ((long long)t * p.ln_rows + row) * 2;
-            s1 += q[0];
-            s2 += q[1];
-        }
-    }
+    if (ok) ln_sum_parts(p.ln_stat + row * 2, (long long)p.ln_rows * 2, p.ln_parts, s1, s2);
     const float mu = s1 * p.ln_inv_c;
     ln_mu[tid] = mu;
     // rows / columns beyond the problem get rstd = 0: their (never stored, or padding) outputs stay finite — a V^T padding column
@@ -896,50 +914,15 @@ constexpr int V5_EPI_BYTES = 16 * V5_EPI_LD * 2;     // one 16-row strip of a wa
 constexpr int V5_SWZ = 0x78;                         // g[x] = (0x78 >> 2x) & 3 = {0, 2, 3, 1}
 
 // one 16-row x 160-column strip of a wave's tile: staged fp16 values -> fused epilogue -> 16-byte global stores
+// EPI (compile time: one epilogue per kernel instantiation keeps its code and its register demand small — with all three inlined
+// into one kernel hipcc spilled 160 registers there and the LayerNorm-folded GEGLU of level 2 ran at 234 us instead of 140):
+//   0 plain (bias / row vector / activation / residual), 1 plain + LayerNorm-fold statistics out, 2 GEGLU
+template <int EPI>
 __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* Cs, int z, int m_base, int n_base, int lane, int part) {
     const bool rows_full = m_base + 16 <= p.M;                          // (wave-uniform) every row of the strip exists: the branch-free paths
-    if (p.act == 2 && rows_full) {   // GEGLU, batched reads + interleaved erf-GELUs (common.h: geglu8_staged)
-        const bool hr = p.R != nullptr;
-        half_t* Cb = p.C + (long long)z * p.sC + (long long)m_base * p.ldc + n_base / 2;
-        const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m_base * p.ldr + n_base / 2 : nullptr;
-        uint4 rba[3], rbg[3], rres[3], ca[3], cg[3];
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int q = lane + it * 64;
-            const int row = q < 160 ? q / 10 : 0, cc = q < 160 ? q - row * 10 : 0;       // (the last pass has 32 live lanes; the others redo chunk 0)
-            rba[it] = ld16(p.bias_n + n_base + cc * 8);
-            rbg[it] = ld16(p.bias_n + n_base + cc * 8 + 80);
-            rres[it] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
-            ca[it] = ld16(Cs + row * V5_EPI_LD + cc * 8);
-            cg[it] = ld16(Cs + row * V5_EPI_LD + 80 + cc * 8);
-        }
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int q = lane + it * 64;
-            const int row = q < 160 ? q / 10 : 0, cc = q < 160 ? q - row * 10 : 0;
-            float a[8], g[8], ba[8], bg[8], r[8];
-            unpack8(ca[it], a);
-            unpack8(cg[it], g);
-            unpack8(rba[it], ba);
-            unpack8(rbg[it], bg);
-            unpack8(rres[it], r);
-            f32x2 ap[4], gp[4], op[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                ap[k] = (f32x2){a[2 * k] + ba[2 * k], a[2 * k + 1] + ba[2 * k + 1]};
-                gp[k] = (f32x2){g[2 * k] + bg[2 * k], g[2 * k + 1] + bg[2 * k + 1]};
-            }
-            geglu8_staged_f32(ap, gp, op);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                a[2 * k] = op[k][0] + r[2 * k];
-                a[2 * k + 1] = op[k][1] + r[2 * k + 1];
-            }
-            if (q < 160) st16(Cb + (long long)row * p.ldc + cc * 8, pack8(a));
-        }
-        return;
-    }
-    if (p.act == 2) {   // GEGLU: the wave's 160 columns are one [80 value | 80 gate] block -> 80 outputs
+    // (GEGLU keeps the predicated loop: with 40 accumulators of the next strips still live, the batched / interleaved form of the 128 x 160
+    // kernel's epilogue spills here and measured 14 % slower per launch at 4096 x 10240 x 1280)
+    if (EPI == 2) {   // GEGLU: the wave's 160 columns are one [80 value | 80 gate] block -> 80 outputs
         uint4 rba[3], rbg[3], rres[3];
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
@@ -971,47 +954,54 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
         return;
     }
     const bool hb = p.bias_n != nullptr, hv = p.rowvec != nullptr, hr = p.R != nullptr;
-    if (rows_full && p.bias_m == nullptr && p.act == 0) {   // branch-free: the five LDS reads and the global operands go out as one batch
+    if (rows_full && p.bias_m == nullptr && p.act == 0) {   // branch-free: LDS reads and global operands go out in batches (3 + 2 chunks: registers)
         half_t* Cb = p.C + (long long)z * p.sC + (long long)m_base * p.ldc + n_base;
         const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m_base * p.ldr + n_base : nullptr;
-        uint4 rb[5], rv[5], rres[5], cv[5], packed[5];
+        float s1[5], s2[5];
 #pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int q = lane + it * 64;
-            const int row = q / 20, cc = q - row * 20;
-            rb[it] = hb ? ld16(p.bias_n + n_base + cc * 8) : zero16();
-            rv[it] = hv ? ld16(p.rowvec + (long long)((m_base + row) / p.rows_per_vec) * p.ldrv + n_base + cc * 8) : zero16();
-            rres[it] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
-            cv[it] = ld16(Cs + row * V5_EPI_LD + cc * 8);
-        }
+        for (int g0 = 0; g0 < 5; g0 += 3) {
+            uint4 rb[3], rv[3], rres[3], cv[3];
 #pragma unroll
-        for (int it = 0; it < 5; ++it) {
-            const int q = lane + it * 64;
-            const int row = q / 20, cc = q - row * 20;
-            float v[8], b[8], e[8], r[8];
-            unpack8(cv[it], v);
-            unpack8(rb[it], b);
-            unpack8(rv[it], e);
-            unpack8(rres[it], r);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] + b[j] + 0.f + e[j] + r[j];          // (the same association as the general loop)
-            packed[it] = pack8(v);
-            st16(Cb + (long long)row * p.ldc + cc * 8, packed[it]);
-        }
-        if (p.stat_out != nullptr) {   // LN-fold producer: row statistics of the stored fp16 values; chunk partials -> LDS -> one lane per row, in chunk order
-            float* sc = reinterpret_cast<float*>(Cs);
-#pragma unroll
-            for (int it = 0; it < 5; ++it) {
-                const int q = lane + it * 64;
-                float f[8], s1 = 0.f, s2 = 0.f;
-                unpack8(packed[it], f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    s1 += f[j];
-                    s2 += f[j] * f[j];
-                }
-                *reinterpret_cast<float2*>(sc + q * 2) = make_float2(s1, s2);
+            for (int k = 0; k < 3; ++k) {
+                if (g0 + k >= 5) continue;
+                const int q = lane + (g0 + k) * 64;
+                const int row = q / 20, cc = q - row * 20;
+                rb[k] = hb ? ld16(p.bias_n + n_base + cc * 8) : zero16();
+                rv[k] = hv ? ld16(p.rowvec + (long long)((m_base + row) / p.rows_per_vec) * p.ldrv + n_base + cc * 8) : zero16();
+                rres[k] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
+                cv[k] = ld16(Cs + row * V5_EPI_LD + cc * 8);
             }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (g0 + k >= 5) continue;
+                const int q = lane + (g0 + k) * 64;
+                const int row = q / 20, cc = q - row * 20;
+                float v[8], b[8], e[8], r[8];
+                unpack8(cv[k], v);
+                unpack8(rb[k], b);
+                unpack8(rv[k], e);
+                unpack8(rres[k], r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] + b[j] + 0.f + e[j] + r[j];      // (the same association as the general loop)
+                const uint4 packed = pack8(v);
+                st16(Cb + (long long)row * p.ldc + cc * 8, packed);
+                if (EPI == 1 && p.stat_out != nullptr) {   // LN-fold producer: row statistics of the stored fp16 values
+                    float f[8];
+                    unpack8(packed, f);
+                    s1[g0 + k] = s2[g0 + k] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        s1[g0 + k] += f[j];
+                        s2[g0 + k] += f[j] * f[j];
+                    }
+                }
+            }
+        }
+        if (EPI == 1 && p.stat_out != nullptr) {   // chunk partials -> LDS (the strip has been consumed) -> one lane per row, in chunk order
+            float* sc = reinterpret_cast<float*>(Cs);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 5; ++it) *reinterpret_cast<float2*>(sc + (lane + it * 64) * 2) = make_float2(s1[it], s2[it]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane < 16) {
                 float a = 0.f, b = 0.f;
@@ -1061,7 +1051,7 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
             }
             const uint4 packed = pack8(v);
             st16(p.C + (long long)z * p.sC + (long long)m * p.ldc + n, packed);
-            if (p.stat_out != nullptr) {   // LN-fold producer: row statistics of what was actually stored (the fp16 values)
+            if (EPI == 1 && p.stat_out != nullptr) {   // LN-fold producer: row statistics of what was actually stored (the fp16 values)
                 float f[8];
                 unpack8(packed, f);
 #pragma unroll
@@ -1072,7 +1062,7 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
             }
         }
     }
-    if (p.stat_out != nullptr) {   // chunk partials -> LDS (the strip has been consumed) -> one lane per row sums them in chunk order
+    if (EPI == 1 && p.stat_out != nullptr) {   // chunk partials -> LDS (the strip has been consumed) -> one lane per row sums them in chunk order
         float* sc = reinterpret_cast<float*>(Cs);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -1098,6 +1088,7 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
 
 // tail shared by the 256 x 320 tile kernels (v5 / v6): split-K slab store, or the staged fused epilogue (two 16-row strips at a
 // time through this wave's 10.5 KB of the — by now quiet — LDS ring)
+template <int EPI, bool LNC>   // EPI: see v5_epilogue_strip; LNC: LayerNorm-fold consumer (ln_mu / ln_rs valid)
 __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][10], char* smem5, const float* ln_mu, const float* ln_rs, int z, int m0,
                                           int n0, int wm0, int wn0, int wid, int lane, int ks, int splitk, int tn_i) {
     constexpr int TM = 4, TN = 10;
@@ -1124,7 +1115,7 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
     // its own 10.5 KB of it, so at most half of the accumulators are live next to the epilogue's prefetch registers
     half_t* Cs = reinterpret_cast<half_t*>(smem5 + wid * 2 * V5_EPI_BYTES);
     const int part = tn_i * 2 + (wid & 1);                          // LN-fold statistics: one part per 160-column half tile
-    const bool ln = p.ln_stat != nullptr;
+    const bool ln = LNC && p.ln_stat != nullptr;
     auto stage = [&](auto I, half_t* dst) {                         // literal strip index: the accumulators stay in registers
         constexpr int i = decltype(I)::value;
         // LN-fold consumer: acc <- rstd * (acc - mu * wsum) in fp32, strip by strip (keeps the live registers low)
@@ -1147,19 +1138,19 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
     stage(std::integral_constant<int, 1>{}, Cs1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: the strips are complete
     __builtin_amdgcn_sched_barrier(0);
-    v5_epilogue_strip(p, Cs, z, m_w, n_w, lane, part);
-    v5_epilogue_strip(p, Cs1, z, m_w + 16, n_w, lane, part);
+    v5_epilogue_strip<EPI>(p, Cs, z, m_w, n_w, lane, part);
+    v5_epilogue_strip<EPI>(p, Cs1, z, m_w + 16, n_w, lane, part);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // strips consumed before the next pair overwrites them
     __builtin_amdgcn_sched_barrier(0);
     stage(std::integral_constant<int, 2>{}, Cs);
     stage(std::integral_constant<int, 3>{}, Cs1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    v5_epilogue_strip(p, Cs, z, m_w + 32, n_w, lane, part);
-    v5_epilogue_strip(p, Cs1, z, m_w + 48, n_w, lane, part);
+    v5_epilogue_strip<EPI>(p, Cs, z, m_w + 32, n_w, lane, part);
+    v5_epilogue_strip<EPI>(p, Cs1, z, m_w + 48, n_w, lane, part);
 }
 
-template <bool CONV>
+template <bool CONV, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
     constexpr int TM = 4, TN = 10;
     __shared__ __attribute__((aligned(16))) char smem5[V5_NST * V5_STAGE_BYTES];
@@ -1305,7 +1296,7 @@ __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
     issue();
     issue();
     if (nk > 2) issue();
-    if (p.ln_stat != nullptr) ln_prepare<V5_BM, V5_BN>(p, ln_mu, ln_rs, z, m0, n0, tid);   // (the loop's barriers publish it)
+    if (EPI != 0 && p.ln_stat != nullptr) ln_prepare<V5_BM, V5_BN>(p, ln_mu, ln_rs, z, m0, n0, tid);   // (the loop's barriers publish it)
     wait_all_but(nk > 2 ? 2 : 1);
     __builtin_amdgcn_s_barrier();
     if (grp1) __builtin_amdgcn_s_barrier();
@@ -1372,7 +1363,7 @@ __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
     }
     if (!grp1) __builtin_amdgcn_s_barrier();                        // group 0 waits out group 1's last MFMA phase: every wave ran 2 nk + 2 barriers
 
-    v5_finish(p, acc, smem5, ln_mu, ln_rs, z, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
+    v5_finish<EPI, EPI != 0>(p, acc, smem5, ln_mu, ln_rs, z, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
 }
 
 // =====================================================================================================================
@@ -1603,7 +1594,7 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     }
     if (!grp1) __builtin_amdgcn_s_barrier();                            // group 0 waits out group 1's last MFMA phase
     if (GN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last ones retire before VALU reads the accumulators
-    v5_finish(p, acc, smem5, nullptr, nullptr, 0, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
+    v5_finish<0, false>(p, acc, smem5, nullptr, nullptr, 0, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
 }
 
 // =====================================================================================================================
@@ -1673,12 +1664,7 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
         if (LN) {
             const int m = mw + i * 16 + fr;
             float s1 = 0.f, s2 = 0.f;
-            if (m < p.M)
-                for (int t = 0; t < p.ln_parts; ++t) {
-                    const float* q = p.ln_stat + ((long long)t * p.ln_rows + m) * 2;
-                    s1 += q[0];
-                    s2 += q[1];
-                }
+            if (m < p.M) ln_sum_parts(p.ln_stat + (long long)m * 2, (long long)p.ln_rows * 2, p.ln_parts, s1, s2);
             const float mu = s1 * p.ln_inv_c;
             mu_a[i] = mu;
             rs_a[i] = rsqrtf(fmaxf(s2 * p.ln_inv_c - mu * mu, 0.f) + p.ln_eps) * p.alpha;     // (rows past M: finite garbage, never stored)
@@ -2260,12 +2246,16 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
                 dim3 grid((unsigned)t5, 1, 1);
                 grid.x = (unsigned)(((p.M + V5_BM - 1) / V5_BM) * (p.N / V5_BN));
                 grid.z = (unsigned)p.batch;
+                const bool ln = p.ln_stat != nullptr || p.stat_out != nullptr;
                 if (p.conv) {
+                    if (ln || p.act == 2) return LD_ERR_ARG;          // (no caller: convolutions carry neither the LayerNorm fold nor GEGLU)
                     t_last_kernel = "gemm5_kernel<256,320,conv>";
-                    hipLaunchKernelGGL((gemm5_kernel<true>), grid, dim3(512), 0, stream, p);
+                    hipLaunchKernelGGL((gemm5_kernel<true, 0>), grid, dim3(512), 0, stream, p);
                 } else {
                     t_last_kernel = "gemm5_kernel<256,320,plain>";
-                    hipLaunchKernelGGL((gemm5_kernel<false>), grid, dim3(512), 0, stream, p);
+                    if (p.act == 2) hipLaunchKernelGGL((gemm5_kernel<false, 2>), grid, dim3(512), 0, stream, p);
+                    else if (ln) hipLaunchKernelGGL((gemm5_kernel<false, 1>), grid, dim3(512), 0, stream, p);
+                    else hipLaunchKernelGGL((gemm5_kernel<false, 0>), grid, dim3(512), 0, stream, p);
                 }
                 return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
             }

@@ -18,7 +18,8 @@ u.set_context(torch.randn(2 * B, 77, 768))
 x = torch.randn(2 * B, 4, hw, hw, device='cuda'); s = torch.full((2 * B,), 3.0, device='cuda')
 runs = {}
 for f in sets:
-    L.ld_debug_gemm_no_v5(f)
+    L.ld_debug_gemm_no_v5(f if f < 1000 else 0)
+    L.ld_debug_gemm_override(f - 1000 if f >= 1000 else 0, 0)     # flag sets >= 1000: force tile height (f - 1000) on the 128 x 160 family
     for _ in range(2): u.forward(x, s)
     torch.cuda.synchronize()
     best = None
@@ -39,6 +40,7 @@ for f in sets:
         else: best = [(min(a[0], b[0]),) + a[1:] for a, b in zip(best, rows)]
     runs[f] = best
 L.ld_debug_gemm_no_v5(0)
+L.ld_debug_gemm_override(0, 0)
 n = len(runs[sets[0]])
 agg = collections.OrderedDict()
 for i in range(n):
