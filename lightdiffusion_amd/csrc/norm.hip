@@ -45,9 +45,29 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
         float s[8], ss[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
-        for (int pix = p_begin + prow; pix < p_end; pix += rows_par) {
+        // four pixels per batch of loads (one load, wait, accumulate per iteration left a wave a single request in flight), summed in
+        // pixel order as before
+        const half_t* src = gn_src(a, n, p_begin + prow, c0);
+        const long long pstep = (long long)rows_par * (c0 < a.C1 ? a.C1 : a.C2);
+        int pix = p_begin + prow;
+        for (; pix + 3 * rows_par < p_end; pix += 4 * rows_par, src += 4 * pstep) {
+            uint4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = ld16(src + u * pstep);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v[8];
+                unpack8(r[u], v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s[j] += v[j];
+                    ss[j] += v[j] * v[j];
+                }
+            }
+        }
+        for (; pix < p_end; pix += rows_par, src += pstep) {
             float v[8];
-            unpack8(ld16(gn_src(a, n, pix, c0)), v);
+            unpack8(ld16(src), v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 s[j] += v[j];
@@ -124,16 +144,29 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
         sc[j] = rstd[g] * ga[j];
         sh[j] = be[j] - mean[g] * sc[j];
     }
-    for (int pix = p_begin + prow; pix < p_end; pix += rows_par) {
+    const half_t* src = gn_src(a, n, p_begin + prow, c0);
+    const long long pstep = (long long)rows_par * (c0 < a.C1 ? a.C1 : a.C2);
+    half_t* dst = a.y + ((long long)n * a.HW + p_begin + prow) * C + c0;
+    const long long dstep = (long long)rows_par * C;
+    auto norm8 = [&](uint4 raw) {
         float v[8];
-        unpack8(ld16(gn_src(a, n, pix, c0)), v);
+        unpack8(raw, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             v[j] = v[j] * sc[j] + sh[j];
             if (a.silu) v[j] = silu_f(v[j]);
         }
-        st16(a.y + ((long long)n * a.HW + pix) * C + c0, pack8(v));
+        return pack8(v);
+    };
+    int pix = p_begin + prow;
+    for (; pix + 3 * rows_par < p_end; pix += 4 * rows_par, src += 4 * pstep, dst += 4 * dstep) {   // four pixels per batch of loads
+        uint4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = ld16(src + u * pstep);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) st16(dst + u * dstep, norm8(r[u]));
     }
+    for (; pix < p_end; pix += rows_par, src += pstep, dst += dstep) st16(dst, norm8(ld16(src)));
 }
 
 // GroupNorm statistics only, finished into per-(image, channel) scale / shift for a consumer that applies them itself (the halo
