@@ -17,7 +17,7 @@ def short_name(k):
     m = re.match(r"gemm(\d)_kernel<(\d+), (\d+), (true|false)(?:, \d+)?>", k)
     if m:
         return f"gemm{m.group(1)}_kernel<{m.group(2)},{m.group(3)},{'conv' if m.group(4) == 'true' else 'plain'}>"
-    m = re.match(r"gemm5_kernel<(true|false)>", k)
+    m = re.match(r"gemm5_kernel<(true|false)(?:, \d+)?>", k)
     if m:
         return f"gemm5_kernel<256,320,{'conv' if m.group(1) == 'true' else 'plain'}>"
     m = re.match(r"conv6_kernel<(\d+), (true|false)>", k)
