@@ -72,11 +72,12 @@ __device__ __forceinline__ float gelu_f(float x) {
 }
 
 // GEGLU products for 8 (value, gate) pairs: ow[k] = fp16x2( a * gelu(g) ) with the erf of gelu_f (Abramowitz-Stegun 7.1.26), written as
-// volatile asm STAGE BY STAGE over 4 register pairs.  Why asm: a wave that shares its SIMD with a partner wave's MFMA stream gets a vector
-// issue slot only when it has an instruction READY — every bubble is taken by an MFMA, which then holds the port for its passes
-// (measured in the row-panel GEMM: 12 clocks per vector instruction with one dependency chain after the other).  hipcc schedules the
-// 40 independent GELUs of a gate step chain by chain whatever the source order (and folds sched_barriers between pure operations), so the
-// interleaving is pinned here: volatile asm statements keep their order.  Packed fp32 where the ISA has it: 12 instructions per product.
+// volatile asm STAGE BY STAGE over 4 register pairs: 4..8 independent instructions between a result and its use (no dependency or
+// transcendental-result bubbles), packed fp32 where the ISA has it, 12 instructions per product.  hipcc schedules the 40 independent GELUs
+// of a gate step chain by chain whatever the source order (and folds sched_barriers between pure operations): volatile asm keeps its order.
+// Measured in the row-panel GEMM's gate step: 5400 -> 5000 clocks.  What is left is the instruction mix itself — about 100 issue cycles per
+// product (2 transcendentals at quarter rate, 6 packed-fp32 operations at half rate) — not contention with the partner wave's MFMA stream:
+// idling that stream with s_nops leaves the 5000 clocks unchanged (profiles/README.md).
 // g: the 8 gates (fp32); values: aw (4 packed fp16 pairs) or af (fp32 pairs); results: ow (4 packed fp16 pairs) or of (fp32 pairs).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool APACKED, bool OPACKED>

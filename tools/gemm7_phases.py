@@ -9,7 +9,7 @@ exec(src)
 cases = [lin(65536, 2560, 320, act=2), lin(65536, 2560, 320), lin(65536, 320, 320, res=True)]
 names = ["mfma issue", "-> barrier A", "epi: issue+aux+phase1", "epi: waits", "epi: phase2+stores", "-> barrier B"]
 for fn, fl, name in cases:
-    for bits in (2048,):
+    for bits in [2048 + int(b) for b in os.environ.get('PH_BITS', '0').split(',')]:
         L.ld_debug_gemm_v5_dbg(bits)
         WS[:4096].zero_()
         fn(); fn(); torch.cuda.synchronize()
