@@ -2079,6 +2079,11 @@ void launch_cfg(const GemmParams& p, hipStream_t s) {
 // tuning hook of the A/B build (tools/gemm_sweep.py): force tile height / split-K for every following launch; 0 = automatic.
 // Not part of the shipped library: `make AB=1` builds libld_mi355x_ab.so with it.
 static int g_force_bm = 0, g_force_sk = 0, g_no_v5 = 0;
+// per-shape override (tools/ab_shape.py: candidates are timed launch by launch INSIDE the forward): M, N, K -> tile height, split
+static int g_shape_ovr[5] = {0, 0, 0, 0, 0};
+extern "C" void ld_debug_gemm_shape_override(int M, int N, int K, int bm, int splitk) {
+    g_shape_ovr[0] = M; g_shape_ovr[1] = N; g_shape_ovr[2] = K; g_shape_ovr[3] = bm; g_shape_ovr[4] = splitk;
+}
 extern "C" void ld_debug_gemm_override(int bm, int splitk) {
     g_force_bm = bm;
     g_force_sk = splitk;
@@ -2144,6 +2149,10 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     p.dbg = g_v5_dbg;
     if (g_force_bm) p.bm = g_force_bm;
     if (g_force_sk) p.splitk = g_force_sk;
+    if (g_shape_ovr[0] == p.M && g_shape_ovr[1] == p.N && g_shape_ovr[2] == p.K && p.batch == 1 && p.gn_scale == nullptr) {
+        p.bm = g_shape_ovr[3];
+        p.splitk = g_shape_ovr[4];
+    }
 #endif
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.A == nullptr || p.W == nullptr || p.C == nullptr) return LD_ERR_ARG;
     if ((p.N & 7) || (p.K & 7) || (p.ldw & 7) || (p.ldc & 7)) return LD_ERR_SHAPE;
@@ -2271,7 +2280,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     const bool skinny_ok = !p.conv && p.act != 2 && p.bn == 0 && p.bm == 0 && (p.N % 64) == 0;
     if (skinny_ok) {
         const long long t160 = (long long)((p.M + 63) / 64) * ((p.N + bn - 1) / bn) * p.batch;
-        if (t160 <= skinny_max) bn = 64;
+        if (t160 <= skinny_max && (p.N + bn - 1) / bn <= 8) bn = 64;      // (wide outputs keep the 160-column tile: 512 x 2560 x 1280 -9 % in the forward)
     }
     if (bn != 128 && bn != 160 && bn != 64) return LD_ERR_ARG;
     if (p.act == 2 && (p.N % bn)) return LD_ERR_SHAPE;
@@ -2286,8 +2295,12 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     const int sk_cap = p.K / 768 < 1 ? 1 : (p.K / 768 > 16 ? 16 : p.K / 768);
     int bm = p.bm, sk = p.splitk;
     if (bm == 0) {
+        // (second and third line re-fitted launch by launch INSIDE the forward, tools/ab_shape.py: an isolated sweep keeps a shape's
+        // weights in L2 / MALL and mis-ranks the candidates.  512 x 1280 x 11520: 64-row tiles + split 8 -11 % against 128 / 15;
+        // 4096 x 1280 x 1280: 128-row tiles -6 %)
         if (tiles128 >= 512) bm = 128;
-        else if (p.K >= 4096 && tiles128 >= 32 && can_split) bm = 128;
+        else if (p.K >= 4096 && can_split && (tiles128 >= 128 || (p.K >= 8192 && tiles128 >= 64))) bm = 128;
+        else if (!p.conv && tiles128 >= 256) bm = 128;
         else bm = 64;
     }
     if (bn == 64) bm = 64;
