@@ -2288,11 +2288,11 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     const int KT = (p.K + BK - 1) / BK;          // 64-wide K slabs
     // Tile height and split-K, fitted to a per-shape sweep of every contraction of the SD1.5 UNet at UNet batch 2 and 16
     // (tools/gemm_sweep.py, profiles/README.md): bigger tiles win whenever they fill the chip; a split only pays when each
-    // slice keeps >= ~768 of K (its second pass is a ~6 us launch plus fp32 slab traffic); short-K problems prefer
+    // slice keeps >= ~640 of K (its second pass is a ~6 us launch plus fp32 slab traffic); short-K problems prefer
     // 64-row tiles and no split; long-K problems prefer 128-row tiles and a split up to ~2 blocks per CU.
     const int tiles128 = ((p.M + 127) / 128) * tiles_n * p.batch;
     const bool can_split = p.batch == 1 && p.partial != nullptr;
-    const int sk_cap = p.K / 768 < 1 ? 1 : (p.K / 768 > 16 ? 16 : p.K / 768);
+    const int sk_cap = p.K / 640 < 1 ? 1 : (p.K / 640 > 16 ? 16 : p.K / 640);   // (640: in-forward sweep, tools/ab_shape.py — 128 x 1280 x 2560: split 4 -14 %)
     int bm = p.bm, sk = p.splitk;
     if (bm == 0) {
         // (second and third line re-fitted launch by launch INSIDE the forward, tools/ab_shape.py: an isolated sweep keeps a shape's
