@@ -146,6 +146,11 @@ int ld_op_axpby(float* x, float a, const float* y, float b, const float* z, floa
  * accumulators of t · (w diag(gamma))^T.  ws: >= 2*N*C + 8*N + 8*((C+63)/64)*M + 1024 bytes. */
 int ld_op_linear_ln(const void* x, const void* w_prod, const void* b_prod, const void* gamma, const void* beta, const void* w,
                     const void* bias, void* t_out, void* y, int M, int C, int N, float eps, void* ws, size_t ws_bytes, void* stream);
+/* The same pair with the GEGLU of FeedForward.net[0] as the consumer (LD.py:4513-4515, 4524-4540): y[M][N/2] = a * gelu(g) with
+ * [a | g] = LayerNorm(t) · w^T + bias — the transformer block's MLP input exactly as the executor runs it (row-panel kernel at C = 320).
+ * ws: >= 4*N*C + 12*N + 8*((C+63)/64)*M + 2048 bytes. */
+int ld_op_linear_ln_geglu(const void* x, const void* w_prod, const void* b_prod, const void* gamma, const void* beta, const void* w,
+                          const void* bias, void* t_out, void* y, int M, int C, int N, float eps, void* ws, size_t ws_bytes, void* stream);
 /* bislerp (LD.py:429-518, LatentUpscale.upscale 6639-6654): fp32 NCHW latents [n][c][h][w] -> [n][c][h_new][w_new];
  * tmp: n*c*h*w_new floats of scratch (the width pass runs first, as in the reference) */
 int ld_op_bislerp(const float* x, float* tmp, float* y, int n, int c, int h, int w, int h_new, int w_new, void* stream);

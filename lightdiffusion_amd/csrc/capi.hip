@@ -214,6 +214,55 @@ int ld_op_linear_ln(const void* x, const void* w_prod, const void* b_prod, const
     return gemm_launch(b, stream);
 }
 
+int ld_op_linear_ln_geglu(const void* x, const void* w_prod, const void* b_prod, const void* gamma, const void* beta, const void* w,
+                          const void* bias, void* t_out, void* y, int M, int C, int N, float eps, void* ws, size_t ws_bytes, void* stream_) {
+    // the transformer block's MLP input as the executor runs it (unet.hip): t = x · w_prod^T + b_prod with row statistics, then
+    //   y[M][N/2] = a * gelu(g),  [a | g] = LayerNorm(t) · w^T + bias     (GEGLU, LD.py:4513-4515, on the LayerNorm-folded weights)
+    // w rows are repacked into the tile-interleaved [value | gate] order first, then folded (the fold is row-wise).
+    if (x == nullptr || w_prod == nullptr || gamma == nullptr || beta == nullptr || w == nullptr || bias == nullptr || t_out == nullptr ||
+        y == nullptr || ws == nullptr)
+        return LD_ERR_ARG;
+    if (!gemm_ln_fold_available()) return LD_ERR_STATE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int bn = gemm_pick_bn(N);
+    if ((N & 15) || (N % bn)) return LD_ERR_SHAPE;
+    const size_t wb = align256((size_t)N * C * sizeof(half_t)), bb = align256((size_t)N * sizeof(half_t)), sb = align256((size_t)N * sizeof(float));
+    const size_t stb = align256((size_t)((C + 63) / 64) * M * 2 * sizeof(float));
+    if (ws_bytes < 2 * wb + 2 * bb + sb + stb) return LD_ERR_ARG;
+    char* wsp = (char*)ws;
+    half_t* wr = (half_t*)wsp;                         // repacked rows
+    half_t* br = (half_t*)(wsp + wb);
+    half_t* w2 = (half_t*)(wsp + wb + bb);             // folded
+    half_t* b2 = (half_t*)(wsp + 2 * wb + bb);
+    float* wsum = (float*)(wsp + 2 * wb + 2 * bb);
+    float* stat = (float*)(wsp + 2 * wb + 2 * bb + sb);
+    int st = repack_rows_launch(w, 0, N, C, wr, bn, stream);
+    if (st == LD_OK) st = repack_rows_launch(bias, 0, N, 1, br, bn, stream);
+    if (st == LD_OK) st = ln_fold_launch(wr, N, C, (const half_t*)gamma, (const half_t*)beta, br, w2, b2, wsum, stream);
+    if (st != LD_OK) return st;
+    int parts = 0;
+    GemmParams a;
+    a.A = (const half_t*)x; a.lda = C;
+    a.W = (const half_t*)w_prod; a.ldw = C;
+    a.M = M; a.N = C; a.K = C;
+    a.bias_n = (const half_t*)b_prod;
+    a.C = (half_t*)t_out; a.ldc = C;
+    a.stat_out = stat; a.stat_parts_out = &parts;
+    st = gemm_launch(a, stream);
+    if (st != LD_OK) return st;
+    GemmParams b;
+    b.A = (const half_t*)t_out; b.lda = C;
+    b.W = w2; b.ldw = C;
+    b.M = M; b.N = N; b.K = C;
+    b.bias_n = b2;
+    b.act = 2; b.bn = bn;
+    b.C = (half_t*)y; b.ldc = N / 2; b.ldr = N / 2;
+    b.ln_stat = stat; b.ln_parts = parts; b.ln_rows = M;
+    b.ln_inv_c = 1.0f / (float)C; b.ln_eps = eps;
+    b.ln_wsum = wsum;
+    return gemm_launch(b, stream);
+}
+
 int ld_op_bislerp(const float* x, float* tmp, float* y, int n, int c, int h, int w, int h_new, int w_new, void* stream) {
     return bislerp_launch(x, tmp, y, n, c, h, w, h_new, w_new, (hipStream_t)stream);
 }

@@ -70,6 +70,20 @@ def linear_ln(x: torch.Tensor, w_prod: torch.Tensor, b_prod: Optional[torch.Tens
     return t, y
 
 
+def linear_ln_geglu(x: torch.Tensor, w_prod: torch.Tensor, b_prod: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                    weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5):
+    """linear_ln with the GEGLU of FeedForward.net[0] as the consumer: t = x @ w_prod.T + b_prod;  [a | g] = LayerNorm(t) @ weight.T + bias;
+    y = a * gelu(g) — the transformer block's MLP input as the executor runs it.  Returns (t, y) with y of width N / 2."""
+    M, C = x.shape
+    N = weight.shape[0]
+    t = torch.empty(M, C, dtype=torch.float16, device=x.device)
+    y = torch.empty(M, N // 2, dtype=torch.float16, device=x.device)
+    ws = _ws(4 * N * C + 12 * N + 8 * ((C + 63) // 64) * M + 4096, x.device)
+    check(lib().ld_op_linear_ln_geglu(_p(x), _p(w_prod), _p(b_prod), _p(gamma), _p(beta), _p(weight), _p(bias), _p(t), _p(y), M, C, N, eps,
+                                      _p(ws), ws.numel(), _stream()), "ld_op_linear_ln_geglu")
+    return t, y
+
+
 def repack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
     """[O,I,kh,kw] (fp16/fp32) -> fp16 [O, kh*kw*I] tap-major / channel-minor, the layout the conv kernels read."""
     O, I, kh, kw = w_oihw.shape

@@ -405,3 +405,23 @@ def test_linear_ln_row_panel(ops):
     assert rel_l2(t.float().cpu(), t_ref.cpu()) < TOL
     y_ref = F.linear(F.layer_norm(t.float(), (C,), gamma.float().to(DEV), beta.float().to(DEV), 1e-5), w.float().to(DEV), b.float().to(DEV))
     assert rel_l2(y.float().cpu(), y_ref.cpu()) < 3e-3
+
+
+@pytest.mark.parametrize("M,C", [(65536, 320), (16384, 640), (4096, 1280), (1000, 320)])
+def test_linear_ln_geglu(ops, M, C):
+    """LayerNorm-folded GEGLU, the MLP input of every transformer block, per level: row-panel kernel with its interleaved erf-GELU and the
+    bias / LayerNorm shift in the accumulator start (C = 320, M >= 49152), the 128 x 160 kernel (C = 640 and the small case), the 256 x 320 one (C = 1280)."""
+    N = 8 * C
+    g = torch.Generator().manual_seed(131 + C)
+    x = (torch.randn(M, C, generator=g) * 1.5 + 0.4).half()
+    wp, bp = (torch.randn(C, C, generator=g) / math.sqrt(C)).half(), (0.1 * torch.randn(C, generator=g)).half()
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).half(), (0.1 * torch.randn(C, generator=g)).half()
+    w, b = (torch.randn(N, C, generator=g) / math.sqrt(C)).half(), (0.1 * torch.randn(N, generator=g)).half()
+    t, y = ops.linear_ln_geglu(x.to(DEV), wp.to(DEV), bp.to(DEV), gamma.to(DEV), beta.to(DEV), w.to(DEV), b.to(DEV))
+    t_ref = F.linear(x.float().to(DEV), wp.float().to(DEV), bp.float().to(DEV))
+    assert rel_l2(t.float().cpu(), t_ref.cpu()) < TOL
+    h = F.linear(F.layer_norm(t.float(), (C,), gamma.float().to(DEV), beta.float().to(DEV), 1e-5), w.float().to(DEV), b.float().to(DEV))
+    a, gt = h.chunk(2, dim=-1)
+    ref = a * F.gelu(gt)
+    assert rel_l2(y.float().cpu(), ref.cpu()) < 3e-3
+    assert (y.float() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item() / 8)
