@@ -108,3 +108,26 @@ def test_cfg_combine_identities(ops):
     assert torch.equal(ops.cfg_combine(den2, 0.0), u)
     mid = ops.cfg_combine(den2, 7.5)
     assert torch.allclose(mid, 0.5 * (ops.cfg_combine(den2, 7.0) + ops.cfg_combine(den2, 8.0)), atol=1e-5)
+
+
+def test_full_size_unet_is_deterministic_and_graph_equals_eager():
+    """No float atomics anywhere and every reduction in a fixed order: the batch-16 SD1.5 forward (config #3's UNet call) gives the same bits
+    twice, and the hipGraph-replayed CFG step the product loop runs gives the bits of the eager one."""
+    from lightdiffusion_amd import weights as W
+    from lightdiffusion_amd.unet import synthetic_unet
+    B = 8
+    u = synthetic_unet(W.sd15_unet_config(), max_batch=2 * B, max_hw=(64, 64))
+    g = torch.Generator().manual_seed(251)
+    ctx = torch.randn(2 * B, 77, 768, generator=g)
+    u.set_context(ctx)
+    x = (torch.randn(2 * B, 4, 64, 64, generator=g) * 4.0).to(DEV)
+    sig = torch.full((2 * B,), 4.0, device=DEV)
+    a = u.forward(x, sig).clone()
+    b = u.forward(x, sig).clone()
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    xb = x[:B].contiguous()
+    d1 = u.cfg_denoise(xb, sig[:B].contiguous(), ctx.to(DEV), 7.5)      # captures, then replays
+    d2 = u.cfg_denoise(xb, sig[:B].contiguous(), ctx.to(DEV), 7.5)
+    assert torch.equal(d1, d2)
+    d3 = u.cfg_denoise(xb, sig[:B].contiguous(), ctx.to(DEV), 7.5, use_graph=False)
+    assert torch.equal(d1, d3)
