@@ -1150,6 +1150,97 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
     v5_epilogue_strip<EPI>(p, Cs1, z, m_w + 48, n_w, lane, part);
 }
 
+// Epilogue of the halo-tile kernel's narrower tiles (256 x 256: the VAE's N = 256 / 512 convolutions; written for any width 16 TN per
+// wave): wave tile 64 x WN, WN = 16 TN.  Convolutions carry no LayerNorm fold and no
+// GEGLU, so this is the plain epilogue only (bias / bias_m / row vector / SiLU / residual), written once for every WN: two 16-row strips
+// at a time through the wave's slice of the (quiet) LDS, operands of a strip requested as one batch, predicated stores.
+template <int TN>
+__device__ __forceinline__ void v6_finish(const GemmParams& p, f32x4 (&acc)[4][TN], char* smem5, int m0, int n0, int wm0, int wn0, int wid, int lane, int ks,
+                                          int splitk) {
+    constexpr int TM = 4, WN = TN * 16, LD = WN + 4, STRIP_BYTES = 16 * LD * 2;
+    constexpr int CPR = WN / 8, TOT = 16 * CPR, ITS = (TOT + 63) / 64;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int m_w = m0 + wm0, n_w = n0 + wn0;
+    if (splitk > 1) {
+        float* part = p.partial + (long long)ks * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m_w + i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (m < p.M) {
+                    f32x4 v = acc[i][j];
+                    v *= p.alpha;
+                    *reinterpret_cast<f32x4*>(part + (long long)m * p.N + n_w + j * 16 + fq * 4) = v;
+                }
+            }
+        }
+        return;
+    }
+    half_t* Cs0 = reinterpret_cast<half_t*>(smem5 + wid * 2 * STRIP_BYTES);
+    const bool hb = p.bias_n != nullptr, hv = p.rowvec != nullptr, hr = p.R != nullptr;
+    auto stage = [&](auto I, half_t* dst) {
+        constexpr int i = decltype(I)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const f32x4 v = acc[i][j] * p.alpha;
+            *reinterpret_cast<uint2*>(dst + fr * LD + j * 16 + fq * 4) = make_uint2(pk2h(v[0], v[1]), pk2h(v[2], v[3]));
+        }
+    };
+    auto strip = [&](const half_t* Cs, int m_base) {
+        uint4 rb[ITS], rv[ITS], rres[ITS], cv[ITS];
+        half_t rm[ITS];
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int q0 = lane + it * 64;
+            const int q = (TOT % 64 == 0 || q0 < TOT) ? q0 : 0;
+            const int row = q / CPR, cc = q - row * CPR;
+            const int m = m_base + row < p.M ? m_base + row : p.M - 1;
+            const int n = n_w + cc * 8;
+            rb[it] = hb ? ld16(p.bias_n + n) : zero16();
+            rv[it] = hv ? ld16(p.rowvec + (long long)(m / p.rows_per_vec) * p.ldrv + n) : zero16();
+            rres[it] = hr ? ld16(p.R + (long long)m * p.ldr + n) : zero16();
+            rm[it] = p.bias_m != nullptr ? p.bias_m[m] : (half_t)0.f;
+            cv[it] = ld16(Cs + row * LD + cc * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            const int q0 = lane + it * 64;
+            const int q = (TOT % 64 == 0 || q0 < TOT) ? q0 : 0;
+            const int row = q / CPR, cc = q - row * CPR;
+            float v[8], b[8], e[8], r[8];
+            unpack8(cv[it], v);
+            unpack8(rb[it], b);
+            unpack8(rv[it], e);
+            unpack8(rres[it], r);
+            const float bm = (float)rm[it];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = v[j] + b[j] + bm + e[j];
+                if (p.act == 1) t = silu_f(t);
+                else if (p.act == 3) t = quick_gelu_f(t);
+                v[j] = t + r[j];
+            }
+            if ((TOT % 64 == 0 || q0 < TOT) && m_base + row < p.M) st16(p.C + (long long)(m_base + row) * p.ldc + n_w + cc * 8, pack8(v));
+        }
+    };
+    half_t* Cs1 = Cs0 + 16 * LD;
+    stage(std::integral_constant<int, 0>{}, Cs0);
+    stage(std::integral_constant<int, 1>{}, Cs1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: the strips are complete
+    __builtin_amdgcn_sched_barrier(0);
+    strip(Cs0, m_w);
+    strip(Cs1, m_w + 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // strips consumed before the next pair overwrites them
+    __builtin_amdgcn_sched_barrier(0);
+    stage(std::integral_constant<int, 2>{}, Cs0);
+    stage(std::integral_constant<int, 3>{}, Cs1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    strip(Cs0, m_w + 32);
+    strip(Cs1, m_w + 48);
+}
+
 template <bool CONV, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
     constexpr int TM = 4, TN = 10;
@@ -1379,17 +1470,21 @@ __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
 // Requirements (gemm_launch): ksize 3, stride 1, pad 1, no resize, Wo == W in {16, 32, 64, 128}, Ho * Wo % 256 == 0,
 // C1 % 32 == 0, C2 % 32 == 0, N % 320 == 0; a split over K is a split over slabs.
 // =====================================================================================================================
-template <int W, bool GN>   // GN: GroupNorm (+SiLU) of the input fused into the halo (separate instantiation: the plain conv keeps its registers)
+template <int W, bool GN, int BN = V5_BN>   // GN: GroupNorm (+SiLU) of the input fused into the halo (separate instantiation: the plain conv keeps its
+                                            // registers); BN: tile width 320 (the UNet's N = 320 k) or 256 (the VAE's N = 256 / 512)
 __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
-    constexpr int TM = 4, TN = 10;
+    constexpr int TM = 4, TN = BN / 32;
+    static_assert(BN == 320 || BN == 256 || BN == 160 || BN == 128, "tile width");
+    static_assert(!GN || BN == V5_BN, "the fused GroupNorm only pays where the output is one 320-column tile wide");
+    constexpr int BPIECES = BN / 16, NB_ALL = BPIECES / 8, NB_EXTRA = BPIECES % 8;   // B pieces of a step: NB_ALL per wave + one more for waves < NB_EXTRA
     constexpr int TR = 256 / W, HW2 = W + 2, HP = (TR + 2) * HW2;      // tile rows, halo row pitch (pixels), halo pixels
     constexpr int NH = ((HP + 15) / 16 + 7) / 8;                      // halo LDS-DMA pieces per wave and slab (uniform: spare pieces copy zeros)
     constexpr int HBYTES = NH * 8 * 1024;                              // one halo buffer
-    constexpr int BSTAGE = V5_BN * 64, NSTB = 4;                       // B ring: 4 stages of 320 rows x 64 bytes
+    constexpr int BSTAGE = BN * 64, NSTB = 4;                          // B ring: 4 stages of BN rows x 64 bytes
     constexpr int RING0 = 2 * HBYTES;                                  // byte offset of the B ring
     __shared__ __attribute__((aligned(16))) char smem5[2 * HBYTES + NSTB * BSTAGE];
     static_assert(2 * HBYTES + NSTB * BSTAGE <= 163840, "LDS");
-    static_assert(3 + NH <= 9, "fused GroupNorm: my pieces of the next slab are normalised in the read phase of tap 3");
+    static_assert(!GN || 3 + NH <= 9, "fused GroupNorm: my pieces of the next slab are normalised in the read phase of tap 3");
     // fused GroupNorm: every wave keeps the 32 scales + 32 shifts of the slab being normalised in 256 bytes of LDS.  Where the
     // halo buffers and the B ring already take all 160 KB (W = 128) the tables live in spare piece slots of halo buffer 0 and the
     // spare (all-zero) pieces of every wave are sent to the last slot instead
@@ -1397,21 +1492,21 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     constexpr bool TBL_IN_HALO = 2 * HBYTES + NSTB * BSTAGE + 2048 > 163840;
     static_assert(!TBL_IN_HALO || NH * 8 - HPIECES >= 3, "two table slots and a dump slot");
     __shared__ __attribute__((aligned(16))) float gn_lds[(GN && !TBL_IN_HALO) ? 8 * 64 : 4];
-    static_assert(8 * 2 * V5_EPI_BYTES <= 2 * HBYTES + NSTB * BSTAGE, "epilogue staging must fit");
+    static_assert(8 * 2 * (BN == V5_BN ? V5_EPI_BYTES : 16 * (BN / 2 + 4) * 2) <= 2 * HBYTES + NSTB * BSTAGE, "epilogue staging must fit");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool grp1 = wid >= 4;
     const int wm = wid >> 1;
-    const int wm0 = wm * 64, wn0 = (wid & 1) * 160;
-    const int tiles_m = p.M / V5_BM, tiles_n = p.N / V5_BN;
+    const int wm0 = wm * 64, wn0 = (wid & 1) * (BN / 2);
+    const int tiles_m = p.M / V5_BM, tiles_n = p.N / BN;
     const int tiles = tiles_m * tiles_n;
     const int splitk = p.splitk > 1 ? p.splitk : 1;
     int bid = xcd_remap(blockIdx.x, tiles * splitk);
     const int ks = bid / tiles;
     bid -= ks * tiles;
     const int tn_i = bid % tiles_n, tm_i = bid / tiles_n;
-    const int m0 = tm_i * V5_BM, n0 = tn_i * V5_BN;
+    const int m0 = tm_i * V5_BM, n0 = tn_i * BN;
     const int Cin = p.C1 + p.C2;
     const int NS = Cin / 32;                                           // channel slabs
     const int s_begin = (int)((long long)ks * NS / splitk), s_end = (int)((long long)(ks + 1) * NS / splitk);
@@ -1477,13 +1572,14 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     };
-    // ---- B loader state (as v5): 2 pieces per wave and step, a third for waves 0-3
+    // ---- B loader state (as v5): NB_ALL pieces per wave and step, one more for waves < NB_EXTRA (BN = 320: 2 + waves 0-3)
     const int prow = lane >> 2;
     const int lchunk = (lane & 3) ^ ((V5_SWZ >> (2 * ((prow >> 2) & 3))) & 3);
-    unsigned b_off[3];
+    const bool b_extra = wid < NB_EXTRA;                                // (wave-uniform)
+    unsigned b_off[NB_ALL + 1];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int piece = i < 2 ? wid * 2 + i : 16 + (wid & 3);
+    for (int i = 0; i < NB_ALL + 1; ++i) {
+        const int piece = i < NB_ALL ? wid * NB_ALL + i : 8 * NB_ALL + (wid % (NB_EXTRA > 0 ? NB_EXTRA : 1));
         const int n = n0 + piece * 16 + prow;
         b_off[i] = (unsigned)(((long long)n * p.ldw + lchunk * 8) * 2);
     }
@@ -1493,8 +1589,8 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     auto issue_b = [&]() {
         const unsigned Bs = smem_base + (unsigned)RING0 + st_issue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16s(b_off[i], b_base, Bs + (unsigned)(wid * 2 + i) * 1024u);
-        if (!grp1) glds16s(b_off[2], b_base, Bs + (unsigned)(16 + wid) * 1024u);
+        for (int i = 0; i < NB_ALL; ++i) glds16s(b_off[i], b_base, Bs + (unsigned)(wid * NB_ALL + i) * 1024u);
+        if (NB_EXTRA > 0 && b_extra) glds16s(b_off[NB_ALL], b_base, Bs + (unsigned)(8 * NB_ALL + wid) * 1024u);
         if (b_tap == 8) {
             b_tap = 0;
             b_base += 32 - 8 * Cin;
@@ -1506,13 +1602,14 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     };
     // "every LDS-DMA of mine but the n newest steps' B pieces (+ the halo pieces when they sit among those) has landed"
     auto wait_keep = [&](int steps, bool halo) {
-        if (!grp1) {
-            if (steps >= 2) { if (halo) wait_vmcnt<6 + NH>(); else wait_vmcnt<6>(); }
-            else if (steps == 1) { if (halo) wait_vmcnt<3 + NH>(); else wait_vmcnt<3>(); }
+        constexpr int PX = NB_ALL + 1, PA = NB_ALL;                      // pieces per step of a wave with / without the extra piece
+        if (NB_EXTRA > 0 && b_extra) {
+            if (steps >= 2) { if (halo) wait_vmcnt<2 * PX + NH>(); else wait_vmcnt<2 * PX>(); }
+            else if (steps == 1) { if (halo) wait_vmcnt<PX + NH>(); else wait_vmcnt<PX>(); }
             else wait_vmcnt<0>();
         } else {
-            if (steps >= 2) { if (halo) wait_vmcnt<4 + NH>(); else wait_vmcnt<4>(); }
-            else if (steps == 1) { if (halo) wait_vmcnt<2 + NH>(); else wait_vmcnt<2>(); }
+            if (steps >= 2) { if (halo) wait_vmcnt<2 * PA + NH>(); else wait_vmcnt<2 * PA>(); }
+            else if (steps == 1) { if (halo) wait_vmcnt<PA + NH>(); else wait_vmcnt<PA>(); }
             else wait_vmcnt<0>();
         }
     };
@@ -1594,7 +1691,8 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     }
     if (!grp1) __builtin_amdgcn_s_barrier();                            // group 0 waits out group 1's last MFMA phase
     if (GN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last ones retire before VALU reads the accumulators
-    v5_finish<0, false>(p, acc, smem5, nullptr, nullptr, 0, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
+    if constexpr (BN == V5_BN) v5_finish<0, false>(p, acc, smem5, nullptr, nullptr, 0, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
+    else v6_finish<TN>(p, acc, smem5, m0, n0, wm0, wn0, wid, lane, ks, splitk);
 }
 
 // =====================================================================================================================
@@ -2108,15 +2206,32 @@ static bool v7_geglu_enabled() {
 }
 
 // does this convolution run on the halo-tile kernel (v6), and with which split over K?
-static bool v6_plan(const GemmParams& p, int* sk_out) {
+static bool v6_plan(const GemmParams& p, int* sk_out, int* bn_out = nullptr) {
     if (!(p.conv && p.ksize == 3 && p.stride == 1 && (p.pad < 0 || p.pad == 1) && p.Hv == p.Hs && p.Wv == p.Ws && p.Ho == p.Hs && p.Wo == p.Ws &&
           (p.Wo == 16 || p.Wo == 32 || p.Wo == 64 || p.Wo == 128) && (p.Ho * p.Wo) % V5_BM == 0 && p.C1 % 32 == 0 && p.C2 % 32 == 0 &&
-          p.N % V5_BN == 0 && p.bm == 0 && p.bn == 0 && p.splitk == 0 && p.batch == 1 && p.act != 2 && p.M % V5_BM == 0))
+          p.bm == 0 && p.bn == 0 && p.splitk == 0 && p.batch == 1 && p.act != 2 && p.M % V5_BM == 0))
         return false;
 #ifdef LD_AB_BUILD
     if (g_no_v5 & 2) return false;
 #endif
-    const long long t6 = (long long)(p.M / V5_BM) * (p.N / V5_BN);
+    // tile width: 320 for the UNet's N = 320 k; 256 for the VAE's N = 256 / 512 at 64- and 128-pixel rows (VAE decode b=8 29.9 -> 28.8 ms).
+    // (256 x 160 tiles for level 1 — 256 unsplit tiles instead of 128 + split — measured a net loss per launch inside the forward:
+    // 16384 x 640 x 5760 737 vs 748 us per 6 launches, but 317 vs 291 / 217 vs 213 / 176 vs 170 us at K = 17280 / 11520 / 8640: a
+    // 64 x 80 wave tile reads 1.3x the LDS bytes per MFMA and halves the MFMAs a step's fixed cost is spread over.)
+    int bn = 0;
+    const long long tm = p.M / V5_BM;
+    if (p.N % V5_BN == 0) {
+        bn = V5_BN;
+    } else if (p.N % 256 == 0 && (p.Wo == 64 || p.Wo == 128) && p.gn_scale == nullptr
+#ifdef LD_AB_BUILD
+               && !(g_no_v5 & 64)
+#endif
+    ) {
+        bn = 256;
+    } else {
+        return false;
+    }
+    const long long t6 = tm * (p.N / bn);
     const int NS = (p.C1 + p.C2) / 32;
     int sk6 = 1;
     // (split over K only from K = 8640 on: per launch inside the UNet forward (tools/ab_launches.py) the split + reduce pair loses to
@@ -2129,6 +2244,7 @@ static bool v6_plan(const GemmParams& p, int* sk_out) {
         while (sk6 > 1 && (size_t)sk6 * p.M * p.N * sizeof(float) > p.partial_bytes) --sk6;
     }
     *sk_out = sk6;
+    if (bn_out != nullptr) *bn_out = bn;
     return t6 * sk6 >= 192;
 }
 
@@ -2140,7 +2256,8 @@ bool gemm_conv_fuses_groupnorm(const GemmParams& p) {
     // tile per M tile), +-0 % at N = 640, -3 % at N = 1280 — every N tile of an M tile normalises the same halo again, so the fusion
     // only pays where the output is one tile wide.
     int sk = 0;
-    return p.N == V5_BN && v6_plan(p, &sk);
+    int bn = 0;
+    return p.N == V5_BN && v6_plan(p, &sk, &bn) && bn == V5_BN;
 }
 
 int gemm_launch(const GemmParams& pin, hipStream_t stream) {
@@ -2173,15 +2290,15 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
 
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     // ---- v6 (halo-tile 3x3 convolution on the v5 skeleton): stride-1 convs whose tiles are whole image rows and fill the chip
-    int sk6 = 0;
-    if (v6_plan(p, &sk6)) {
-        const long long t6 = (long long)(p.M / V5_BM) * (p.N / V5_BN);
+    int sk6 = 0, bn6 = 0;
+    if (v6_plan(p, &sk6, &bn6)) {
+        const long long t6 = (long long)(p.M / V5_BM) * (p.N / bn6);
         p.splitk = sk6;
         p.pad = 1;
         p.n_valid = p.N;
         dim3 grid((unsigned)(t6 * sk6), 1, 1);
         if (p.gn_scale != nullptr) {
-            if (p.gn_shift == nullptr) return LD_ERR_ARG;
+            if (p.gn_shift == nullptr || bn6 != V5_BN) return LD_ERR_ARG;
             t_last_kernel = p.Wo == 16 ? "conv6_kernel<W16,halo+groupnorm>" : p.Wo == 32 ? "conv6_kernel<W32,halo+groupnorm>"
                           : p.Wo == 64 ? "conv6_kernel<W64,halo+groupnorm>" : "conv6_kernel<W128,halo+groupnorm>";
             switch (p.Wo) {
@@ -2190,6 +2307,10 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
                 case 64: hipLaunchKernelGGL((conv6_kernel<64, true>), grid, dim3(512), 0, stream, p); break;
                 default: hipLaunchKernelGGL((conv6_kernel<128, true>), grid, dim3(512), 0, stream, p); break;
             }
+        } else if (bn6 == 256) {
+            t_last_kernel = p.Wo == 64 ? "conv6_kernel<W64,halo,256>" : "conv6_kernel<W128,halo,256>";
+            if (p.Wo == 64) hipLaunchKernelGGL((conv6_kernel<64, false, 256>), grid, dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((conv6_kernel<128, false, 256>), grid, dim3(512), 0, stream, p);
         } else {
             t_last_kernel = p.Wo == 16 ? "conv6_kernel<W16,halo>" : p.Wo == 32 ? "conv6_kernel<W32,halo>" : p.Wo == 64 ? "conv6_kernel<W64,halo>" : "conv6_kernel<W128,halo>";
             switch (p.Wo) {

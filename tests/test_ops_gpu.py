@@ -276,7 +276,11 @@ def test_geglu_big_tiles(ops, M, C):
     (16, 64, 64, 640, 320, 320, 1, None, True, True),      # halo kernel, W = 64, two sources (output-block ResBlock conv1)
     (64, 16, 16, 1280, 0, 1280, 1, None, False, True),     # halo kernel, W = 16: a tile is one whole 16x16 image
     (4, 128, 128, 320, 0, 320, 1, None, True, False),      # halo kernel, W = 128 (hires latents): two image rows per tile
-    (16, 32, 32, 64, 0, 640, 1, None, False, False)])      # halo kernel, W = 32, two 32-channel slabs only
+    (16, 32, 32, 64, 0, 640, 1, None, False, False),       # halo kernel, W = 32, two 32-channel slabs only
+    (16, 32, 32, 640, 0, 640, 1, None, True, True),        # level-1 ResBlock conv (K = 5760: the 128 x 160 kernel, no split)
+    (8, 64, 64, 512, 0, 512, 1, None, False, True),        # halo kernel, 256 x 256 tiles, W = 64 (VAE decoder, 64 x 64 stage)
+    (2, 128, 128, 512, 0, 256, 1, None, False, False),     # halo kernel, 256 x 256 tiles, W = 128, one N tile (VAE 512 -> 256 at 128 x 128)
+    (3, 64, 64, 256, 0, 256, 1, None, True, True)])        # 256 x 256 tiles, 192 tiles: just fills the chip
 def test_conv3x3_big_tiles(ops, n, h, w, c1, c2, cout, stride, out_hw, rv, res):
     x1 = r16((n, c1, h, w), 91)
     x2 = r16((n, c2, h, w), 92) if c2 else None
