@@ -354,7 +354,7 @@ def test_groupnorm_silu_conv(ops, n, h, w, c1, c2, cout, rv, res):
 # ------------------------------------------------------------------ the row-panel kernel (gemm7_kernel): K = 320, A fragments in registers
 @pytest.mark.parametrize("M,N,bias,res,act", [
     (65536, 320, True, True, "none"), (65536, 640, False, False, "none"), (50001, 320, True, False, "silu"), (49152, 960, True, True, "quick_gelu"),
-    (65536, 80, True, False, "none")])
+    (65536, 80, True, False, "none"), (50001, 640, True, True, "none"), (49999, 320, False, False, "none")])   # (ragged M: the row-panel kernel's predicated last panel)
 def test_linear_row_panel(ops, M, N, bias, res, act):
     K = 320
     x, w = r16((M, K), 111), r16((N, K), 112, 1 / math.sqrt(K))
@@ -380,10 +380,10 @@ def test_linear_row_panel(ops, M, N, bias, res, act):
     assert rel_l2(y[rows].float().cpu(), ref_cpu) < TOL
 
 
-@pytest.mark.parametrize("res", [False, True])
-def test_geglu_row_panel(ops, res):
-    """GEGLU at K = 320 (without a residual: the row-panel kernel with its interleaved erf-GELU; with one: the 128 x 160 kernel)."""
-    M, C = 65536, 320
+@pytest.mark.parametrize("res,M", [(False, 65536), (True, 65536), (False, 50001)])
+def test_geglu_row_panel(ops, res, M):
+    """GEGLU at K = 320 (without a residual: the row-panel kernel with its interleaved erf-GELU — also with a ragged last panel; with one: the 128 x 160 kernel)."""
+    C = 320
     x, w, b = r16((M, C), 115), r16((8 * C, C), 116, 1 / math.sqrt(C)), r16((8 * C,), 117, 0.1)
     r = r16((M, 4 * C), 118) if res else None
     y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), None if r is None else r.to(DEV), act="geglu")
