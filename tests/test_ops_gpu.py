@@ -411,7 +411,7 @@ def test_linear_ln_row_panel(ops):
     assert rel_l2(y.float().cpu(), y_ref.cpu()) < 3e-3
 
 
-@pytest.mark.parametrize("M,C", [(65536, 320), (16384, 640), (4096, 1280), (1000, 320)])
+@pytest.mark.parametrize("M,C", [(65536, 320), (16384, 640), (4096, 1280), (1000, 320), (50001, 320)])
 def test_linear_ln_geglu(ops, M, C):
     """LayerNorm-folded GEGLU, the MLP input of every transformer block, per level: row-panel kernel with its interleaved erf-GELU and the
     bias / LayerNorm shift in the accumulator start (C = 320, M >= 49152), the 128 x 160 kernel (C = 640 and the small case), the 256 x 320 one (C = 1280)."""
