@@ -13,9 +13,18 @@ __global__ __launch_bounds__(256) void small_conv_in_kernel(const SmallConvInArg
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     half_t* wl = reinterpret_cast<half_t*>(smem_raw);           // transposed filter bank [9*CIN][Cout]: 8 couts = one 16-byte read
     constexpr int KK = 9 * CIN;
-    for (int i = threadIdx.x; i < a.Cout * KK; i += blockDim.x) {
-        const int o = i / KK, k = i - o * KK;
-        wl[k * a.Cout + o] = a.w[i];
+    if ((KK & 3) == 0) {   // 8-byte reads of the row-major bank, scattered into the transposed copy (2-byte reads made this prologue most of the batch-1 launch)
+        for (int i = threadIdx.x; i < a.Cout * KK / 4; i += blockDim.x) {
+            const int o = (i * 4) / KK, k = i * 4 - o * KK;
+            const half4 v = *reinterpret_cast<const half4*>(a.w + (long long)i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wl[(k + e) * a.Cout + o] = v[e];
+        }
+    } else {
+        for (int i = threadIdx.x; i < a.Cout * KK; i += blockDim.x) {
+            const int o = i / KK, k = i - o * KK;
+            wl[k * a.Cout + o] = a.w[i];
+        }
     }
     float pw[CIN][CIN], pb[CIN];
     if (a.pre_w != nullptr) {
@@ -315,7 +324,8 @@ int small_conv_out_launch(const SmallConvOutArgs& a, hipStream_t stream) {
     const int nch = (9 * (a.Cin >> 3) + 63) / 64;        // chunks a lane owns
     if (nch > 9) return LD_ERR_SHAPE;                    // Cin <= 512
     const long long npix = (long long)a.N * a.H * a.W;
-    long long waves = npix / 16;                         // >= 16 pixels per wave amortise the weight preload
+    long long waves = npix / 16;                         // >= 16 pixels per wave amortise the weight preload ...
+    if (waves < 2048) waves = npix / 4 < 2048 ? npix / 4 : 2048;   // ... but a batch-1 latent (8192 pixels) must still fill the chip's 1024 SIMDs
     if (waves > 8192) waves = 8192;
     if (waves < 4) waves = 4;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
