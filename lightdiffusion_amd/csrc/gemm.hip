@@ -2150,7 +2150,7 @@ const char* intern_name(const std::string& s) {   // stable storage for composed
 }
 
 template <int BM, int BN>
-void launch_cfg(const GemmParams& p, hipStream_t s) {
+void launch_cfg(const GemmParams& p, hipStream_t s, bool deep = false) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int sk = p.splitk > 1 ? p.splitk : 1;
     dim3 grid(tiles * sk, 1, p.batch);
@@ -2163,6 +2163,12 @@ void launch_cfg(const GemmParams& p, hipStream_t s) {
     } else if (p.conv) {
         static const std::string name = "gemm3_kernel<" + std::to_string(BM) + "," + std::to_string(BN) + ",conv>";
         t_last_kernel = name.c_str();
+        if constexpr (BM == 64 && BN == 160) {
+            if (deep) {   // 4-stage ring, one workgroup per CU (three slabs in flight): see the rule in gemm_launch
+                hipLaunchKernelGGL((gemm3_kernel<BM, BN, true, 4>), grid, dim3(NT), 0, s, p);
+                return;
+            }
+        }
         hipLaunchKernelGGL((gemm3_kernel<BM, BN, true, 2>), grid, dim3(NT), 0, s, p);
     } else {
         static const std::string name = "gemm3_kernel<" + std::to_string(BM) + "," + std::to_string(BN) + ",plain>";
@@ -2427,10 +2433,18 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (bn == 64) bm = 64;
     if (bm != 64 && bm != 128) return LD_ERR_ARG;
     const int tiles = ((p.M + bm - 1) / bm) * tiles_n;
+    // Convolutions on 64 x 160 tiles with very few tiles (<= 32: the 8 x 8 level of a batch-1 step) or exactly one round of them (256 .. 511)
+    // run the 4-stage ring with ONE workgroup per CU and a split aimed at 256 workgroups: three slabs in flight per workgroup hide the
+    // HBM latency of their cold weights better than two co-resident 2-stage workgroups (per launch inside the batch-1 forward,
+    // tools/ab_launches.py: 128 x 1280 x 11520 24.3 -> 22.2 us, 8192 x 320 x 1600 32 -> 26 us; 64 .. 128 tiles with long K lose 10 %).
+    bool deep = p.conv && bm == 64 && bn == 160 && p.batch == 1 && p.splitk == 0 && (tiles <= 32 || (tiles >= 256 && tiles < 512));
+#ifdef LD_AB_BUILD
+    if (g_no_v5 & 128) deep = false;
+#endif
     if (sk == 0) {
         sk = 1;
         if (can_split && tiles * p.batch < 512) {
-            sk = (512 + tiles - 1) / tiles;
+            sk = ((deep ? 256 : 512) + tiles - 1) / tiles;
             if (sk > sk_cap) sk = sk_cap;
         }
     }
@@ -2453,7 +2467,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (bn == 64) launch_cfg<64, 64>(p, stream);
     else if (bm == 128 && bn == 160) launch_cfg<128, 160>(p, stream);
     else if (bm == 128 && bn == 128) launch_cfg<128, 128>(p, stream);
-    else if (bm == 64 && bn == 160) launch_cfg<64, 160>(p, stream);
+    else if (bm == 64 && bn == 160) launch_cfg<64, 160>(p, stream, deep);
     else launch_cfg<64, 128>(p, stream);
 
     if (sk > 1) {
