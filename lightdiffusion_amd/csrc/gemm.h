@@ -59,6 +59,13 @@ struct GemmParams {
     const float* gn_scale = nullptr;   // [n_img][C1 + C2] fp32: rstd * gamma
     const float* gn_shift = nullptr;   // [n_img][C1 + C2] fp32: beta - mean * rstd * gamma
     int gn_silu = 0;
+    // ---- GroupNorm statistics of THIS contraction's output, emitted by its split-K second pass (the reduce kernel touches every output
+    //   element anyway): per (image, pixel chunk, group) partial (sum, sum of squares) in exactly the layout, thread mapping and summation
+    //   order of norm.hip's gn_stats_kernel, so the GroupNorm that follows skips its statistics launch and produces the same bits.
+    //   Honoured only when the launch splits over K (otherwise *gn_part_done stays 0 and the caller runs the statistics pass).
+    float* gn_part = nullptr;          // [n_img][gn_P][32][2] floats
+    int gn_P = 0, gn_ppb = 0, gn_HW = 0;
+    int* gn_part_done = nullptr;       // host int, set to 1 when the partials were written
     int dbg = 0;                 // A/B build only (LD_AB_BUILD): ablation switches of the v5 kernel (timing runs, wrong results)
 };
 

@@ -2136,6 +2136,91 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     }
 }
 
+// split-K second pass that also emits the GroupNorm partial statistics of its output (GemmParams::gn_part): block = (pixel chunk, image,
+// slab of 8 groups), a thread owns one 8-channel chunk and strides over the chunk's pixels — thread mapping, LDS layout and summation
+// order are those of gn_stats_kernel (norm.hip), so the partials (and the normalised tensor) are bit-identical to the two-launch path.
+__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const GemmParams p) {
+    __shared__ float csum[2048], csq[2048];   // [rows_par][slab channels]
+    const int C = p.N, cpg = C / 32;
+    const int CS = C / 4, CHS = CS >> 3;
+    const int n = blockIdx.y, pc = blockIdx.x, slab = blockIdx.z, tid = threadIdx.x;
+    const int rows_par = 256 / CHS;
+    const int cc = tid % CHS, prow = tid / CHS;
+    const int c0 = slab * CS + cc * 8;
+    const int p_begin = pc * p.gn_ppb, p_end = min(p.gn_HW, p_begin + p.gn_ppb);
+    const long long slab_stride = (long long)p.M * p.N;
+    if (prow < rows_par) {
+        float s[8], ss[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+        for (int pix = p_begin + prow; pix < p_end; pix += rows_par) {
+            const int m = n * p.gn_HW + pix;
+            const float* base = p.partial + (long long)m * p.N + c0;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            int sp = 0;
+            for (; sp + 4 <= p.splitk; sp += 4) {
+                f32x4 x0[4], x1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    x0[u] = *reinterpret_cast<const f32x4*>(base + (sp + u) * slab_stride);
+                    x1[u] = *reinterpret_cast<const f32x4*>(base + (sp + u) * slab_stride + 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] += x0[u][j];
+                        v[4 + j] += x1[u][j];
+                    }
+            }
+            for (; sp < p.splitk; ++sp) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(base + sp * slab_stride), x1 = *reinterpret_cast<const f32x4*>(base + sp * slab_stride + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] += x0[j];
+                    v[4 + j] += x1[j];
+                }
+            }
+            epilogue_store8(p, 0, m, c0, c0, v);                       // (v comes back as the values before the fp16 rounding)
+            float f[8];
+            unpack8(pack8(v), f);                                      // statistics of what was stored: the fp16 values, as gn_stats_kernel reads them
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += f[j];
+                ss[j] += f[j] * f[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            csum[prow * CS + cc * 8 + j] = s[j];
+            csq[prow * CS + cc * 8 + j] = ss[j];
+        }
+    }
+    __syncthreads();
+    {
+        const int g = tid >> 5, sub = tid & 31;                  // 8 groups x 32 lanes
+        const int cnt = rows_par * cpg;
+        float a = 0.f, b = 0.f;
+        for (int i = sub; i < cnt; i += 32) {
+            const int pr = i / cpg, c = g * cpg + (i - pr * cpg);
+            a += csum[pr * CS + c];
+            b += csq[pr * CS + c];
+        }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            a += __shfl_xor(a, o, 64);
+            b += __shfl_xor(b, o, 64);
+        }
+        if (sub == 0) {
+            float* o = p.gn_part + (((long long)n * p.gn_P + pc) * 32 + slab * 8 + g) * 2;
+            o[0] = a;
+            o[1] = b;
+        }
+    }
+}
+
 // plain GEMMs with at most this many workgroups take the producer/consumer kernel (measured at B=1: 256 -> 169.3, 512 -> 167.8,
 // 768 -> 166.2, 1280 -> 164.8 steps/s)
 constexpr int V4_MAX_BLOCKS = 256;
@@ -2196,6 +2281,24 @@ extern "C" void ld_debug_gemm_no_v5(int off) { g_no_v5 = off; }
 static int g_v5_dbg = 0;
 extern "C" void ld_debug_gemm_v5_dbg(int bits) { g_v5_dbg = bits; }   // 1: no DMA issue in the loop, 2: no fragment reads, 4: 4 of 40 MFMAs
 #endif
+
+// the split-K second pass of a launch: the plain reduce, or the one that also emits GroupNorm partials (GemmParams::gn_part)
+static void launch_splitk_reduce(const GemmParams& p, int bn, hipStream_t stream) {
+    const bool gn = p.gn_part != nullptr && p.act != 2 && p.batch == 1 && p.gn_P > 0 && p.gn_HW > 0 && p.M % p.gn_HW == 0 && p.N % 32 == 0 && p.N <= 8192 &&
+                    p.ldc == p.N && (p.N / 4) % 8 == 0 && p.N / 32 <= 256;
+    if (gn) {
+        hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3(p.gn_P, p.M / p.gn_HW, 4), dim3(256), 0, stream, p);
+        if (p.gn_part_done != nullptr) *p.gn_part_done = 1;
+        t_last_kernel = intern_name(std::string(t_last_kernel) + "+splitk_reduce_gn_kernel");
+        return;
+    }
+    const int out_n = p.act == 2 ? p.N / 2 : p.N;
+    const long long total = (long long)p.M * (out_n / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, bn);
+    t_last_kernel = intern_name(std::string(t_last_kernel) + "+splitk_reduce_kernel");
+}
 
 bool gemm_ln_fold_available() { return true; }
 const char* gemm_last_kernel_name() { return t_last_kernel; }
@@ -2326,13 +2429,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
                 default: hipLaunchKernelGGL((conv6_kernel<128, false>), grid, dim3(512), 0, stream, p); break;
             }
         }
-        if (sk6 > 1) {
-            const long long total = (long long)p.M * (p.N / 8);
-            int blocks = (int)((total + 255) / 256);
-            if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, 160);
-            t_last_kernel = intern_name(std::string(t_last_kernel) + "+splitk_reduce_kernel");
-        }
+        if (sk6 > 1) launch_splitk_reduce(p, 160, stream);
         return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
     }
     if (p.gn_scale != nullptr) return LD_ERR_ARG;   // only the halo kernel applies a fused GroupNorm (ask gemm_conv_fuses_groupnorm first)
@@ -2470,13 +2567,6 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     else if (bm == 64 && bn == 160) launch_cfg<64, 160>(p, stream, deep);
     else launch_cfg<64, 128>(p, stream);
 
-    if (sk > 1) {
-        const int out_n = p.act == 2 ? p.N / 2 : p.N;
-        const long long total = (long long)p.M * (out_n / 8);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p, bn);
-        t_last_kernel = intern_name(std::string(t_last_kernel) + "+splitk_reduce_kernel");
-    }
+    if (sk > 1) launch_splitk_reduce(p, bn, stream);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }

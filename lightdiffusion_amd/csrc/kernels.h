@@ -19,10 +19,10 @@ static inline int gn_num_chunks(int n_img, int HW) {
 }
 size_t groupnorm_workspace_bytes(int n_img, int HW);
 int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, const half_t* gamma,
-                     const half_t* beta, float eps, int silu, half_t* y, float* partial, hipStream_t stream);
+                     const half_t* beta, float eps, int silu, half_t* y, float* partial, hipStream_t stream, int stats_ready = 0);
 // statistics pass + finalize only: scale / shift [n_img][C1 + C2] fp32 for a consumer that normalises on the fly (gemm.h gn_scale)
 int groupnorm_scale_shift_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, const half_t* gamma, const half_t* beta,
-                                 float eps, float* partial, float* scale, float* shift, hipStream_t stream);
+                                 float eps, float* partial, float* scale, float* shift, hipStream_t stream, int stats_ready = 0);
 int layernorm_launch(const half_t* x, const half_t* gamma, const half_t* beta, half_t* y, int rows, int C, float eps,
                      hipStream_t stream);
 // in-place row softmax over fp16 scores; cols and ld multiples of 8; valid (0 = cols): columns >= valid are padding (written as 0)

@@ -300,7 +300,7 @@ size_t groupnorm_workspace_bytes(int n_img, int HW) {
 }
 
 int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, const half_t* gamma,
-                     const half_t* beta, float eps, int silu, half_t* y, float* partial, hipStream_t stream) {
+                     const half_t* beta, float eps, int silu, half_t* y, float* partial, hipStream_t stream, int stats_ready) {
     const int C = C1 + C2;
     if (x1 == nullptr || y == nullptr || partial == nullptr || gamma == nullptr || beta == nullptr) return LD_ERR_ARG;
     if (C % 32 || C1 % 8 || C2 % 8 || C > 8192 || C1 <= 0 || (C2 > 0 && x2 == nullptr)) return LD_ERR_SHAPE;
@@ -310,13 +310,13 @@ int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_i
     a.ppb = (HW + a.P - 1) / a.P;
     a.partial = partial; a.gamma = gamma; a.beta = beta; a.y = y; a.eps = eps; a.silu = silu;
     dim3 grid(a.P, n_img, GN_SLABS);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, stream, a);
+    if (!stats_ready) hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, stream, a);   // (ready: the producer's split-K reduce wrote `partial`, gemm.h gn_part)
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), 0, stream, a);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
 
 int groupnorm_scale_shift_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, const half_t* gamma, const half_t* beta,
-                                 float eps, float* partial, float* scale, float* shift, hipStream_t stream) {
+                                 float eps, float* partial, float* scale, float* shift, hipStream_t stream, int stats_ready) {
     const int C = C1 + C2;
     if (x1 == nullptr || partial == nullptr || gamma == nullptr || beta == nullptr || scale == nullptr || shift == nullptr) return LD_ERR_ARG;
     if (C % 32 || C1 % 8 || C2 % 8 || C > 8192 || C1 <= 0 || (C2 > 0 && x2 == nullptr)) return LD_ERR_SHAPE;
@@ -325,7 +325,7 @@ int groupnorm_scale_shift_launch(const half_t* x1, int C1, const half_t* x2, int
     a.P = gn_num_chunks(n_img, HW);
     a.ppb = (HW + a.P - 1) / a.P;
     a.partial = partial; a.gamma = gamma; a.beta = beta; a.y = nullptr; a.eps = eps; a.silu = 0;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.P, n_img, GN_SLABS), dim3(GN_THREADS), 0, stream, a);
+    if (!stats_ready) hipLaunchKernelGGL(gn_stats_kernel, dim3(a.P, n_img, GN_SLABS), dim3(GN_THREADS), 0, stream, a);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img, GN_SLABS), dim3(GN_THREADS), 0, stream, a, scale, shift);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }

@@ -203,34 +203,38 @@ struct Exec {
         note(gemm_launch(p, stream));
         t_end(gemm_last_kernel_name());
     }
+    // `ready`: partial statistics the producer's split-K reduce already wrote (gemm.h gn_part): the statistics launch is skipped
     void groupnorm(const half_t* x1, int C1, const half_t* x2, int C2, int n, int HW, const half_t* g, const half_t* b, float eps,
-                   int silu, half_t* y) {
+                   int silu, half_t* y, float* ready = nullptr) {
         const size_t m = arena->mark();
-        float* ws = reinterpret_cast<float*>(arena->alloc(groupnorm_workspace_bytes(n, HW)));
-        launches += 2;
-        t_begin(KC_GNORM, 0.0, 2, "groupnorm", n, HW, C1 + C2, silu);
-        if (!dry && status == LD_OK) note(groupnorm_launch(x1, C1, x2, C2, n, HW, g, b, eps, silu, y, ws, stream));
-        t_end("gn_stats_kernel+gn_apply_kernel");
+        float* ws = ready != nullptr ? ready : reinterpret_cast<float*>(arena->alloc(groupnorm_workspace_bytes(n, HW)));
+        const int nl = ready != nullptr ? 1 : 2;
+        launches += nl;
+        t_begin(KC_GNORM, 0.0, nl, "groupnorm", n, HW, C1 + C2, silu);
+        if (!dry && status == LD_OK) note(groupnorm_launch(x1, C1, x2, C2, n, HW, g, b, eps, silu, y, ws, stream, ready != nullptr));
+        t_end(ready != nullptr ? "gn_apply_kernel" : "gn_stats_kernel+gn_apply_kernel");
         arena->release(m);
     }
     // GroupNorm(32) + SiLU feeding a 3x3 convolution.  When the convolution runs on the halo-tile kernel the normalisation is fused
     // into its A operand: only the statistics pass + a tiny finalize run here (scale / shift per image and channel), the conv reads the
     // RAW tensor(s) — no normalised copy is written or read back.  Otherwise: the two-pass GroupNorm into `g` (caller-provided), then the conv.
     // `p`: the convolution with A / A2 = the RAW sources; returns through p.C as usual.
-    void gn_silu_conv(GemmParams p, int n_img, int HW, const half_t* gamma, const half_t* beta, float eps, half_t* g) {
+    // `ready`: GroupNorm partial statistics of the input that its producer already wrote (see groupnorm)
+    void gn_silu_conv(GemmParams p, int n_img, int HW, const half_t* gamma, const half_t* beta, float eps, half_t* g, float* ready = nullptr) {
         p.partial = splitk_ws;
         p.partial_bytes = splitk_bytes;
         if (gemm_conv_fuses_groupnorm(p)) {
             const int C = p.C1 + p.C2;
             const size_t m = arena->mark();
-            float* ws = reinterpret_cast<float*>(arena->alloc(groupnorm_workspace_bytes(n_img, HW)));
+            float* ws = ready != nullptr ? ready : reinterpret_cast<float*>(arena->alloc(groupnorm_workspace_bytes(n_img, HW)));
             float* scale = reinterpret_cast<float*>(arena->alloc((size_t)n_img * C * sizeof(float)));
             float* shift = reinterpret_cast<float*>(arena->alloc((size_t)n_img * C * sizeof(float)));
-            launches += 2;
-            t_begin(KC_GNORM, 0.0, 2, "gn_stats", n_img, HW, C, 1);
+            const int nl = ready != nullptr ? 1 : 2;
+            launches += nl;
+            t_begin(KC_GNORM, 0.0, nl, "gn_stats", n_img, HW, C, 1);
             if (!dry && status == LD_OK)
-                note(groupnorm_scale_shift_launch(p.A, p.C1, p.A2, p.C2, n_img, HW, gamma, beta, eps, ws, scale, shift, stream));
-            t_end("gn_stats_kernel+gn_finalize_kernel");
+                note(groupnorm_scale_shift_launch(p.A, p.C1, p.A2, p.C2, n_img, HW, gamma, beta, eps, ws, scale, shift, stream, ready != nullptr));
+            t_end(ready != nullptr ? "gn_finalize_kernel" : "gn_stats_kernel+gn_finalize_kernel");
             p.gn_scale = scale;
             p.gn_shift = shift;
             p.gn_silu = 1;
@@ -238,7 +242,7 @@ struct Exec {
             arena->release(m);
             return;
         }
-        groupnorm(p.A, p.C1, p.A2, p.C2, n_img, HW, gamma, beta, eps, 1, g);
+        groupnorm(p.A, p.C1, p.A2, p.C2, n_img, HW, gamma, beta, eps, 1, g, ready);
         p.A = g;
         p.A2 = nullptr;
         p.C1 = p.C1 + p.C2;

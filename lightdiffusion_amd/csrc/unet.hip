@@ -313,8 +313,18 @@ struct Run {
         };
         half_t* g1 = ar.halfs(M * r.cin);
         half_t* h1 = ar.halfs(M * r.cout);
-        ex.gn_silu_conv(conv_params(x1, C1, x2, C2, r.c1_w, r.c1_b, emb_all + r.emb_off, u->emb_total, nullptr, h1), n, H * W, P(r.gn1_g), P(r.gn1_b),
-                        1e-5f, g1);
+        // the GroupNorm statistics of h1 (out_layers' norm) come from conv1's split-K second pass where it has one (gemm.h gn_part)
+        float* gnp = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(n, H * W)));
+        int gnp_done = 0;
+        {
+            GemmParams c1 = conv_params(x1, C1, x2, C2, r.c1_w, r.c1_b, emb_all + r.emb_off, u->emb_total, nullptr, h1);
+            c1.gn_part = gnp;
+            c1.gn_P = gn_num_chunks(n, H * W);
+            c1.gn_HW = H * W;
+            c1.gn_ppb = (c1.gn_HW + c1.gn_P - 1) / c1.gn_P;
+            c1.gn_part_done = &gnp_done;
+            ex.gn_silu_conv(c1, n, H * W, P(r.gn1_g), P(r.gn1_b), 1e-5f, g1);
+        }
         half_t* g2 = g1;   // g1 is dead once conv1 has consumed it (stream order); reuse when it is large enough
         if (r.cout > r.cin) g2 = ar.halfs(M * r.cout);
         const half_t* skip = x1;
@@ -323,7 +333,8 @@ struct Run {
             conv3(x1, C1, x2, C2, H, W, H, W, 1, r.sk_w, r.sk_b, r.cout, nullptr, 0, nullptr, sk, nullptr, nullptr, 1);
             skip = sk;
         }
-        ex.gn_silu_conv(conv_params(h1, r.cout, nullptr, 0, r.c2_w, r.c2_b, nullptr, 0, skip, out), n, H * W, P(r.gn2_g), P(r.gn2_b), 1e-5f, g2);
+        ex.gn_silu_conv(conv_params(h1, r.cout, nullptr, 0, r.c2_w, r.c2_b, nullptr, 0, skip, out), n, H * W, P(r.gn2_g), P(r.gn2_b), 1e-5f, g2,
+                        gnp_done ? gnp : nullptr);
         ar.release(mk);
         return {out, r.cout, H, W};
     }
