@@ -12,9 +12,10 @@ from lightdiffusion_amd._lib import lib
 from lightdiffusion_amd.unet import synthetic_unet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 L = lib()
-u = synthetic_unet(W.sd15_unet_config(), max_batch=2 * B, max_hw=(64, 64))
+hw = int(os.environ.get("AB_HW", "64"))
+u = synthetic_unet(W.sd15_unet_config(), max_batch=2 * B, max_hw=(hw, hw))
 u.set_context(torch.randn(2 * B, 77, 768))
-x = torch.randn(2 * B, 4, 64, 64, device='cuda'); s = torch.full((2 * B,), 3.0, device='cuda')
+x = torch.randn(2 * B, 4, hw, hw, device='cuda'); s = torch.full((2 * B,), 3.0, device='cuda')
 
 
 def profile():
