@@ -46,6 +46,77 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("LD_BENCH_CPU_THREADS", "16"))))
 
 
+def lib_hash():
+    """sha256 (first 16 hex digits) of the HIP library this process loads: ties PMC traffic numbers to the kernels that are timed."""
+    import hashlib
+    from lightdiffusion_amd._lib import LIB_PATH
+    with open(LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def launch_min_bytes(what, dims):
+    """Minimal HBM bytes of one launch (fp16 unless noted): every input and the weights read once, the output written once.
+    Contractions: the RAW input pixels x Cin (not the im2col matrix) + W + C;  attention: Q + K + V^T + O;  GroupNorm: read + write."""
+    a, b, c, d = dims
+    if what in ("conv3", "conv1", "gemm", "geglu"):
+        cin = c // 9 if what == "conv3" else c
+        n_out = b // 2 if what == "geglu" else b
+        return 2.0 * d * (a * cin + b * c + a * n_out)
+    if what == "attention":        # (batch*heads, Lq, Lk, d)
+        return 2.0 * a * (2 * b * d + 2 * c * d)
+    if what in ("groupnorm", "gn_stats"):   # (images, pixels, channels, silu)
+        return 2.0 * a * b * c * (2 if what == "groupnorm" else 1)
+    if what == "conv_in":
+        return 2.0 * a * b + 4.0 * a * 4
+    if what == "conv_out":
+        return 2.0 * a * c / 9 + 4.0 * a * b
+    if what == "softmax":
+        return 4.0 * a * b
+    return 0.0
+
+
+RIDGE = 2.5e15 / 8.0e12      # FLOP per HBM byte above which a launch is MFMA-bound (SURVEY 8d: ~315)
+
+
+def rooflines(rows, ms_by_kernel, traffic_for):
+    """rows: per-launch (what, dims, flops, us, kernel) of one profiled run; ms_by_kernel: averaged ms per kernel name.
+    -> (roofline of the kernel that takes the most time, roofline of the dominant HBM-bound kernel or None).  A kernel is priced
+    against the roof its arithmetic intensity (algorithmic FLOPs / minimal bytes) puts it under."""
+    agg = {}
+    for what, dims, fl, us, kern in rows:
+        a = agg.setdefault(kern, {"flops": 0.0, "bytes": 0.0, "n": 0})
+        a["flops"] += fl
+        a["bytes"] += launch_min_bytes(what, dims)
+        a["n"] += 1
+
+    def one(kern):
+        a = agg[kern]
+        ms = ms_by_kernel.get(kern)
+        if not ms or a["bytes"] <= 0:
+            return None
+        hbm = a["flops"] / a["bytes"] < RIDGE
+        tr, tr_d, tr_from = traffic_for(kern)
+        out = {"kernel": kern, "bound": "hbm" if hbm else "mfma", "launches": a["n"], "avg_launch_us": 1e3 * ms / a["n"],
+               "flops_per_launch": a["flops"] / a["n"], "min_bytes_per_launch": a["bytes"] / a["n"],
+               "intensity_flop_per_byte": a["flops"] / a["bytes"], "traffic": tr, "traffic_detail": tr_d, "traffic_from": tr_from}
+        if hbm:
+            ach = a["bytes"] / (ms * 1e-3)
+            out.update(achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
+                       also_tflops=a["flops"] / (ms * 1e-3) / 1e12)
+        else:
+            ach = a["flops"] / (ms * 1e-3)
+            out.update(achieved=ach / 1e12, peak=MFMA_PEAK_F16 / 1e12, unit="TFLOP/s", frac=ach / MFMA_PEAK_F16)
+        return out
+
+    timed = [k for k in agg if ms_by_kernel.get(k)]
+    if not timed:
+        return None, None
+    dom = max(timed, key=lambda k: ms_by_kernel[k])
+    hb = [k for k in timed if agg[k]["bytes"] > 0 and agg[k]["flops"] / agg[k]["bytes"] < RIDGE and agg[k]["flops"] > 0]
+    dom_h = max(hb, key=lambda k: ms_by_kernel[k]) if hb else None
+    return one(dom), (one(dom_h) if dom_h else None)
+
+
 def spawn_ranks(n, argv):
     """`--gpus N` without a torchrun environment: start N fresh rank processes (this process never touches the GPU)."""
     port = 29400 + os.getpid() % 400
@@ -71,6 +142,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip batch-1 / hires / e2e / cpu baseline (profiling runs)")
     ap.add_argument("--only", default=None, choices=[None, "batch8", "batch1", "hires"], help="time just one workload (profiling runs)")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-prime", action="store_true", help="skip the set-up pass (graph capture + one schedule pass) before the warm-up steps")
+    ap.add_argument("--reps", type=int, default=5, help="extra one-pass brackets after the timed region (median ms/step); 0 for profiling runs")
+    ap.add_argument("--sync-steps", action="store_true",
+                    help="synchronize after every sampler step: bounds the host's run-ahead (rocprofv3 --pmc passes: profiles/README.md round 3)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -81,6 +156,18 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}, "
                          f"or pass --gpus alone and let bench.py start the ranks")
+
+    dbg = os.environ.get("LD_BENCH_DEBUG")          # <path prefix>: fault / hang tracebacks and /proc/self/maps for post-mortems under a profiler
+    if dbg:
+        import faulthandler
+        fh = open(dbg + ".fault", "w")
+        faulthandler.enable(file=fh, all_threads=True)
+        faulthandler.dump_traceback_later(int(os.environ.get("LD_BENCH_DEBUG_HANG_S", "60")), repeat=True, file=fh)
+
+    def dump_maps(tag):
+        if dbg:
+            with open("/proc/self/maps") as src, open(f"{dbg}.maps", "w") as dst:
+                dst.write(f"# {tag}\n" + src.read())
 
     import torch
     if not torch.cuda.is_available():
@@ -109,6 +196,7 @@ def main():
     unet = synthetic_unet(cfg, max_batch=2 * args.batch, max_hw=(64, 64), device=dev)
     t_load = time.time() - t0
     log(f"weights resident in {t_load:.1f}s: {unet.weight_bytes / 2**20:.0f} MiB weights, {unet.workspace_bytes / 2**20:.0f} MiB workspace")
+    dump_maps("weights resident")
     model = nodes._attach(unet, dev)                      # ModelPatcher + set_model_unet_function_wrapper: the reference's plugin seam
     if args.no_graph:
         model.model_options["ld_use_graph"] = False
@@ -130,6 +218,21 @@ def main():
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tp):
         traffic_db = json.load(open(tp))
+    my_lib = lib_hash()
+
+    def traffic_lookup(tag):
+        """PMC bytes per launch (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, rocprofv3 --pmc passes of THIS bench.py, tools/prof_run.sh) — only
+        when the pass was taken with the library that is loaded now (`lib` hash in the tag); otherwise null + where it would come from."""
+        t = traffic_db.get(tag) or {}
+        ok = t.get("_lib") == my_lib
+
+        def f(kern):
+            d = t.get(kern.split("+")[0])
+            if not isinstance(d, dict):
+                return None, None, None
+            src = f"profiles/pmc_traffic.json[{tag}] lib {t.get('_lib')}" + ("" if ok else f" (stale: loaded library is {my_lib})")
+            return (d.get("hbm_bytes_per_launch"), d, src) if ok else (None, None, src)
+        return f
 
     def barrier():
         if world > 1:
@@ -147,14 +250,22 @@ def main():
         latent = torch.zeros(B, 4, L, L) if denoise is None else torch.randn(B, 4, L, L, generator=gen) * 0.8
         noise = torch.randn(B, 4, L, L, generator=gen)
 
+        cb = (lambda d: torch.cuda.synchronize()) if args.sync_steps else None
+
         def passes(nsteps):
             done = 0
             while done < nsteps:
                 n = min(run_len, nsteps - done)
                 sampling.sample(model, noise, pos, neg, cfg_scale, dev, sampling.ksampler(sampler, opts), sig[: n + 1], model.model_options,
-                                latent_image=latent, seed=rank)
+                                latent_image=latent, callback=cb, seed=rank)
                 done += n
+                dump_maps(f"{tag}: {done} steps")
 
+        # set-up, before the W warm-up steps (like loading the weights): the first call of a shape plans the workspace and captures
+        # the step's hipGraph; one schedule pass brings the clocks out of idle
+        if not args.no_prime:
+            passes(run_len)
+            torch.cuda.synchronize()
         passes(Wm)
         barrier()
         t0 = time.perf_counter()
@@ -168,7 +279,7 @@ def main():
             elapsed = float(t.item())
         # repetitions (after the contract's bracket): 5 more brackets of one schedule pass each -> median ms/step
         reps = []
-        for _ in range(5):
+        for _ in range(args.reps):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             passes(run_len)
@@ -186,27 +297,23 @@ def main():
                 agg[name] = (a[0] + msv, fl, nl)
         agg = {k: (v[0] / 3.0, v[1], v[2]) for k, v in agg.items()}
         cls = {k: (v[0] / 3.0, v[1], v[2]) for k, v in cls.items()}
-        dom = max((k for k in agg if agg[k][1] > 0), key=lambda k: agg[k][0])
-        d_ms, d_fl, d_n = agg[dom]
+        rows = unet.profile_launches()                              # per launch of the last profiled forward: shapes, FLOPs, kernel
+        roof, roof_hbm = rooflines(rows, {k: v[0] for k, v in agg.items()}, traffic_lookup(tag))
         step_flops = unet.last_flops
-        tr_d = traffic_db.get(tag, {}).get(dom.split("+")[0])      # PMC passes exist for the headline workload (profiles/README.md)
-        tr = tr_d.get("hbm_bytes_per_launch") if tr_d else None   # FETCH_SIZE x 2 (gfx950) + WRITE_SIZE, rocprofv3 --pmc, profiles/*_pmc.csv
         res = {
             "workload": f"SD1.5 512x512 UNet CFG step, {sampler} / {scheduler}-{sched_steps}, batch {B}/GPU (UNet batch {2 * B}), latent {L}x{L}",
             "steps_per_s": world * K / elapsed, "ms_per_step": 1e3 * elapsed / K, "steps": K,
-            "ms_per_step_median_of_5_passes": statistics.median(reps), "ms_per_step_passes": [round(r, 4) for r in reps],
+            "ms_per_step_median_of_5_passes": statistics.median(reps) if reps else None, "ms_per_step_passes": [round(r, 4) for r in reps],
             "unet_evals_per_s": world * K * 2 * B / elapsed,
             "step_tflops": step_flops / 1e12,
             "mfma_frac_whole_step": step_flops * K / elapsed / MFMA_PEAK_F16,
             "launches_per_forward": unet.last_launches,
             "kernel_class_ms_per_forward": {k: round(v[0], 4) for k, v in cls.items()},
             "kernels_ms_per_forward": {k: [round(v[0], 4), v[2]] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:8]},
-            "roofline": {"kernel": dom, "bound": "mfma", "achieved": d_fl / (d_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_F16 / 1e12,
-                         "unit": "TFLOP/s", "frac": (d_fl / (d_ms * 1e-3)) / MFMA_PEAK_F16,
-                         "traffic": tr, "traffic_detail": tr_d, "launches": d_n, "avg_launch_us": 1e3 * d_ms / max(d_n, 1), "flops_per_launch": d_fl / max(d_n, 1)},
+            "roofline": roof, "roofline_hbm": roof_hbm,
         }
         log(f"{tag}: {K} steps in {elapsed:.3f}s -> {res['steps_per_s']:.2f} steps/s ({res['unet_evals_per_s']:.0f} UNet-evals/s); "
-            f"dominant {dom} {res['roofline']['achieved']:.0f} TFLOP/s")
+            f"dominant {roof['kernel']} {roof['achieved']:.0f} {roof['unit']} ({roof['bound']} roof, {100 * roof['frac']:.1f} %)")
         return res
 
     K, Wm = args.steps, args.warmup
@@ -237,9 +344,19 @@ def main():
                 ts.append(time.perf_counter() - t1)
             return statistics.median(ts)
 
+        def vae_roofs(v, z, tag):
+            """dominant kernels of one decode (HIP events per launch, median of 3 profiled decodes), priced like the UNet's"""
+            runs = [v.profile_decode(z) for _ in range(3)]
+            ms = {}
+            for i, r in enumerate(runs[0]):
+                ms[r[4]] = ms.get(r[4], 0.0) + statistics.median(rr[i][3] for rr in runs) * 1e-3
+            return rooflines(runs[0], ms, traffic_lookup(tag))
+
         t_vae = timed(lambda: vae.decode_device(lat))
+        r_m, r_h = vae_roofs(vae, lat, "vae512")
         out_extra["vae_decode_512"] = {"batch": args.batch, "ms": 1e3 * t_vae, "images_per_s": args.batch / t_vae,
-                                       "tflops": vae.last_flops / t_vae / 1e12}
+                                       "tflops": vae.last_flops / t_vae / 1e12, "launches": vae.last_launches,
+                                       "roofline": r_m, "roofline_hbm": r_h}
         # end to end: 20-step DPM++ 2M txt2img at batch B through the node-level sampler + VAE decode (CLIP not included:
         # the conditioning is synthetic), latents stay on the device between the two
         ks20 = sampling.KSampler1(model, steps=20, device=dev, sampler="dpmpp_2m_sde", scheduler="karras", denoise=None,
@@ -258,7 +375,9 @@ def main():
         vae = synthetic_vae(W.sd15_vae_config(), max_batch=4, max_hw=(128, 128), device=dev)
         lat = torch.randn(4, 4, 128, 128, generator=torch.Generator().manual_seed(7)) * 4.0
         t_v2 = timed(lambda: vae.decode_device(lat), n=2)
-        out_extra["vae_decode_1024"] = {"batch": 4, "ms": 1e3 * t_v2, "images_per_s": 4 / t_v2, "tflops": vae.last_flops / t_v2 / 1e12}
+        r_m, r_h = vae_roofs(vae, lat, "vae1024")
+        out_extra["vae_decode_1024"] = {"batch": 4, "ms": 1e3 * t_v2, "images_per_s": 4 / t_v2, "tflops": vae.last_flops / t_v2 / 1e12,
+                                        "roofline": r_m, "roofline_hbm": r_h}
         del vae
         torch.cuda.empty_cache()
 
@@ -272,6 +391,8 @@ def main():
         "dtype": "f16 (fp32 accumulate)", "data": "synthetic latents + random-init SD1.5 weights",
         "config": {"workload": head["workload"], "global_batch": args.batch * world,
                    "parallelism": f"dp{world} (replicas, RCCL cond broadcast)", "hip_graph": not args.no_graph,
+                   "setup_before_warmup": None if args.no_prime else "hipGraph capture + one untimed schedule pass per workload",
+                   "library_sha256_16": my_lib,
                    "timed_loop": "lightdiffusion_amd.sampling.sample (product call surface)"},
         "unet_evals_per_s": head["unet_evals_per_s"],
         "step_tflops": head["step_tflops"], "mfma_frac_whole_step": head["mfma_frac_whole_step"],

@@ -77,6 +77,9 @@ int ld_unet_profile(ld_unet* u, const float* x, const float* sigma, float* out, 
 /* per kernel INSTANTIATION (the names rocprofv3 --kernel-trace lists, abbreviated) of the last ld_unet_profile call:
  * one text line "name<TAB>launches<TAB>total ms<TAB>algorithmic FLOPs" each, NUL-terminated.  LD_ERR_ARG if buf is too small. */
 int ld_unet_profile_kernels(const ld_unet* u, char* buf, size_t buf_bytes);
+/* per LAUNCH of the last ld_unet_profile call, in launch order: "what<TAB>M<TAB>N<TAB>K<TAB>batch<TAB>algorithmic FLOPs<TAB>
+ * microseconds<TAB>kernel" (contractions; GroupNorm rows carry images / pixels / channels / silu, attention rows batch*heads / Lq / Lk / d) */
+int ld_unet_profile_launches(const ld_unet* u, char* buf, size_t buf_bytes);
 /* number of kernel launches of the last forward, and algorithmic FLOPs of it (2*M*N*K over every contraction) */
 int ld_unet_last_launches(const ld_unet* u);
 double ld_unet_last_flops(const ld_unet* u);
@@ -103,6 +106,10 @@ int ld_vae_decode(ld_vae* v, const float* z, float* out, int b, int h, int w, vo
 /* VAE.encode's device part (LD.py:6383-6410): pixels fp32 NCHW [b][3][8h][8w] in [-1,1] -> moments fp32 NCHW [b][2z][h][w]
  * (mean | logvar, before DiagonalGaussianRegularizer's host-RNG sample, LD.py:3446-3458); (h, w) = latent size */
 int ld_vae_encode(ld_vae* v, const float* pixels_nchw, float* moments, int b, int h, int w, void* stream);
+/* ld_vae_decode with a HIP-event pair around every launch (recorded on `stream`; synchronises it), and the per-launch table of that
+ * run in the format of ld_unet_profile_launches: the per-layer VAE table of profiles/ (TFLOP/s and bytes per stage) is built from it */
+int ld_vae_profile(ld_vae* v, const float* z, float* out, int b, int h, int w, void* stream);
+int ld_vae_profile_launches(const ld_vae* v, char* buf, size_t buf_bytes);
 int ld_vae_last_launches(const ld_vae* v);
 double ld_vae_last_flops(const ld_vae* v);
 

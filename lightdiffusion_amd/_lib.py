@@ -53,6 +53,7 @@ SIGNATURES = {
     "ld_unet_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "ld_unet_profile": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I)]),
     "ld_unet_profile_kernels": (_I, [_P, C.c_char_p, _Z]),
+    "ld_unet_profile_launches": (_I, [_P, C.c_char_p, _Z]),
     "ld_unet_last_launches": (_I, [_P]),
     "ld_unet_last_flops": (C.c_double, [_P]),
     "ld_vae_create": (_I, [C.POINTER(VAEConfig), C.POINTER(_P)]),
@@ -64,6 +65,8 @@ SIGNATURES = {
     "ld_vae_workspace_bytes": (_Z, [_P]),
     "ld_vae_decode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ld_vae_encode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ld_vae_profile": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "ld_vae_profile_launches": (_I, [_P, C.c_char_p, _Z]),
     "ld_vae_last_launches": (_I, [_P]),
     "ld_vae_last_flops": (C.c_double, [_P]),
     "ld_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _Z, _P]),

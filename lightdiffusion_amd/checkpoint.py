@@ -204,6 +204,7 @@ class LoraMergeResult(int):
     unet = 0
     clip = 0
     unmatched: tuple = ()
+    missing_down: tuple = ()
 
 
 def merge_lora(sd: Dict[str, torch.Tensor], lora: Dict[str, torch.Tensor], strength: float = 1.0, strength_clip: Optional[float] = None,
@@ -219,12 +220,18 @@ def merge_lora(sd: Dict[str, torch.Tensor], lora: Dict[str, torch.Tensor], stren
     n_unet = n_clip = 0
     seen = set()
     modules = sorted({k[:-len(".lora_up.weight")] for k in lora if k.endswith(".lora_up.weight")})
-    for name in modules:
-        up, down = lora[name + ".lora_up.weight"], lora.get(name + ".lora_down.weight")
-        key = km.get(name)
-        if key is None or down is None:
-            continue
-        seen.add(name)
+    present = set(modules)
+    no_down = tuple(m for m in modules if m + ".lora_down.weight" not in lora)
+    # one patch per TARGET weight, as the reference keys its patch_dict (`patch_dict[to_load[x]] = ...`, LD.py:549-575, iterating the
+    # key map): a file that names one weight through two aliases (ldm- and diffusers-flattened `lora_unet_*`, `unet.` + bare
+    # processor key) patches it once — the alias that comes last in key-map order wins
+    patches: Dict[str, str] = {}
+    for name, key in km.items():
+        if name in present and name + ".lora_down.weight" in lora:
+            patches[key] = name
+            seen.add(name)
+    for key, name in patches.items():
+        up, down = lora[name + ".lora_up.weight"], lora[name + ".lora_down.weight"]
         is_clip = key.startswith(clip_prefix)
         scale = sc if is_clip else strength
         if name + ".alpha" in lora:
@@ -236,7 +243,10 @@ def merge_lora(sd: Dict[str, torch.Tensor], lora: Dict[str, torch.Tensor], stren
         n_unet += not is_clip
     res = LoraMergeResult(n_unet + n_clip)
     res.unet, res.clip = n_unet, n_clip
-    res.unmatched = tuple(m for m in modules if m not in seen)
+    res.unmatched = tuple(m for m in modules if m not in seen and m not in no_down)
+    res.missing_down = no_down
+    if no_down:
+        warnings.warn(f"LoRA: {len(no_down)} module(s) have lora_up but no lora_down weight and were not applied: " + ", ".join(no_down[:4]))
     if res.unmatched:
         warnings.warn(f"LoRA: {len(res.unmatched)} module(s) match no layer of this checkpoint and were not applied: "
                       + ", ".join(res.unmatched[:4]) + (" ..." if len(res.unmatched) > 4 else ""))

@@ -111,6 +111,12 @@ struct Timing {
         int launches = 0;
     };
     std::vector<std::pair<std::string, PerKernel>> per_kernel;   // filled by collect(), in first-seen order
+    struct Launch {                  // one record per timed launch (ld_*_profile_launches)
+        const char* what = "";
+        long long a = 0, b = 0, d = 0, e = 0;
+        float us = 0.f;
+    };
+    std::vector<Launch> rec;
     bool verbose = false;
     size_t used = 0;
     double ms[KC_COUNT] = {0}, flops[KC_COUNT] = {0};
@@ -130,6 +136,7 @@ struct Timing {
         kname.clear();
         kflops.clear();
         per_kernel.clear();
+        rec.clear();
         verbose = getenv("LD_PROFILE_DUMP") != nullptr;
         for (int i = 0; i < KC_COUNT; ++i) ms[i] = flops[i] = 0, launches[i] = 0;
     }
@@ -145,12 +152,27 @@ struct Timing {
             per_kernel[j].second.ms += t;
             per_kernel[j].second.flops += i / 2 < kflops.size() ? kflops[i / 2] : 0.0;
             per_kernel[j].second.launches += 1;
+            if (i / 2 < rec.size()) rec[i / 2].us = t * 1e3f;
             if (verbose && i / 2 < desc.size()) fprintf(stderr, "[ld_profile] %8.1f us  %s  %s\n", t * 1e3, desc[i / 2].c_str(), kn);
         }
     }
     void destroy() {
         for (hipEvent_t e : ev) (void)hipEventDestroy(e);
         ev.clear();
+    }
+    // "what\ta\tb\tc\td\tflops\tmicroseconds\tkernel\n" per timed launch of the last profiled run, in launch order
+    int format_launches(char* buf, size_t buf_bytes) const {
+        if (buf == nullptr || buf_bytes == 0) return LD_ERR_ARG;
+        size_t off = 0;
+        buf[0] = 0;
+        for (size_t i = 0; i < rec.size(); ++i) {
+            const Launch& r = rec[i];
+            const int w = snprintf(buf + off, buf_bytes - off, "%s\t%lld\t%lld\t%lld\t%lld\t%.0f\t%.2f\t%s\n", r.what, r.a, r.b, r.d, r.e,
+                                   i < kflops.size() ? kflops[i] : 0.0, r.us, i < kname.size() && kname[i] ? kname[i] : "?");
+            if (w < 0 || (size_t)w >= buf_bytes - off) return LD_ERR_ARG;   // buffer too small
+            off += (size_t)w;
+        }
+        return LD_OK;
     }
 };
 
@@ -181,6 +203,10 @@ struct Exec {
         timing->flops[c] += fl;
         timing->launches[c] += nl;
         timing->kflops.push_back(fl);
+        Timing::Launch r;
+        r.what = what;
+        r.a = a; r.b = b; r.d = d; r.e = e;
+        timing->rec.push_back(r);
         (void)hipEventRecord(timing->next(), stream);
     }
     void t_end(const char* kernel_name = "misc") {

@@ -827,6 +827,11 @@ int ld_unet_profile_kernels(const ld_unet* u, char* buf, size_t buf_bytes) {
     return LD_OK;
 }
 
+int ld_unet_profile_launches(const ld_unet* u, char* buf, size_t buf_bytes) {
+    if (u == nullptr) return LD_ERR_ARG;
+    return u->timing.format_launches(buf, buf_bytes);
+}
+
 int ld_unet_last_launches(const ld_unet* u) { return u ? u->last_launches : 0; }
 double ld_unet_last_flops(const ld_unet* u) { return u ? u->last_flops : 0.0; }
 

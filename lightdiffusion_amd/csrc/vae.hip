@@ -43,6 +43,8 @@ struct ld_vae {
     int plan_b = 0, plan_h = 0, plan_w = 0;
     int last_launches = 0;
     double last_flops = 0.0;
+    Timing timing;
+    bool want_timing = false;
 };
 
 namespace {
@@ -241,7 +243,9 @@ struct VRun {
             ex.gemm(p);
         }
         ex.launches += 1;
+        ex.t_begin(KC_MISC, 0.0, 1, "softmax", (long long)n * L, Lp, 0, 1);
         if (!ex.dry && ex.status == LD_OK) ex.note(softmax_rows_launch(s, n * L, Lp, Lp, ex.stream, L));
+        ex.t_end("softmax_rows_kernel");
         half_t* o = g;   // reuse
         {   // O_b = P_b V_b  (W operand = V^T [C][Lp]; the pad keys carry zero probability)
             GemmParams p;
@@ -275,6 +279,10 @@ int run_decode(ld_vae* v, bool dry, const float* z, float* out, int b, int h, in
     ex.arena = dry ? &plan : &v->arena;
     ex.splitk_ws = v->splitk_ws;
     ex.splitk_bytes = v->splitk_bytes;
+    if (v->want_timing && !dry) {
+        v->timing.reset();
+        ex.timing = &v->timing;
+    }
     Arena& ar = *ex.arena;
     ar.release(0);
     const ld_vae_config& c = v->cfg;
@@ -288,7 +296,9 @@ int run_decode(ld_vae* v, bool dry, const float* z, float* out, int b, int h, in
         a.N = b; a.Cin = c.z_channels; a.H = H; a.W = W; a.Cout = C;
         ex.launches += 1;
         ex.flops += 2.0 * b * H * W * C * 9.0 * c.z_channels;
+        ex.t_begin(KC_MISC, 2.0 * b * H * W * C * 9.0 * c.z_channels, 1, "conv_in", (long long)b * H * W, C, 9 * c.z_channels, 1);
         if (!dry) ex.note(small_conv_in_launch(a, stream));
+        ex.t_end("small_conv_in_kernel");
     }
     f = R.resblock(v->mid1, f, H, W);
     f = R.attn(v->mid_attn, f, H, W);
@@ -314,7 +324,9 @@ int run_decode(ld_vae* v, bool dry, const float* z, float* out, int b, int h, in
         a.N = b; a.H = H; a.W = W; a.Cin = C; a.Cout = c.out_ch; a.mode = 1; a.out = out;
         ex.launches += 1;
         ex.flops += 2.0 * b * H * W * C * 9.0 * c.out_ch;
+        ex.t_begin(KC_MISC, 2.0 * b * H * W * C * 9.0 * c.out_ch, 1, "conv_out", (long long)b * H * W, c.out_ch, 9 * C, 1);
         if (!dry) ex.note(small_conv_out_launch(a, stream));
+        ex.t_end("small_conv_out_kernel");
     }
     v->last_launches = ex.launches;
     v->last_flops = ex.flops;
@@ -409,6 +421,7 @@ int ld_vae_create(const ld_vae_config* cfg, ld_vae** out) {
 void ld_vae_destroy(ld_vae* v) {
     if (v == nullptr) return;
     v->pt.destroy();
+    v->timing.destroy();
     if (v->ws_base) (void)hipFree(v->ws_base);
     delete v;
 }
@@ -489,6 +502,22 @@ int ld_vae_encode(ld_vae* v, const float* pixels_nchw, float* moments, int b, in
     if (peak > v->arena.cap) return LD_ERR_SHAPE;
     v->plan_b = v->plan_h = v->plan_w = 0;   // the decode plan cache does not cover encode shapes
     return run_encode(v, false, pixels_nchw, moments, b, h, w, (hipStream_t)stream);
+}
+
+int ld_vae_profile(ld_vae* v, const float* z, float* out, int b, int h, int w, void* stream) {
+    if (v == nullptr) return LD_ERR_ARG;
+    v->want_timing = true;
+    const int st = ld_vae_decode(v, z, out, b, h, w, stream);
+    v->want_timing = false;
+    if (st != LD_OK) return st;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return LD_ERR_HIP;
+    v->timing.collect();
+    return LD_OK;
+}
+
+int ld_vae_profile_launches(const ld_vae* v, char* buf, size_t buf_bytes) {
+    if (v == nullptr) return LD_ERR_ARG;
+    return v->timing.format_launches(buf, buf_bytes);
 }
 
 int ld_vae_last_launches(const ld_vae* v) { return v ? v->last_launches : 0; }

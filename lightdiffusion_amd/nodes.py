@@ -121,18 +121,22 @@ def bislerp(samples: torch.Tensor, width: int, height: int, device=None) -> torc
     from . import ops
     if samples.is_cuda:
         return ops.bislerp(samples, width, height)
-    dev = torch.device(device if device is not None else "cuda:0")
+    # one rank per GPU: the default is THIS process's current device, never a hard-coded cuda:0
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
     return ops.bislerp(samples.to(dev), width, height).to(samples.device)
 
 
 class LatentUpscale:
     upscale_methods = ["nearest-exact", "bilinear", "area", "bicubic", "bislerp"]
 
+    def __init__(self, device=None):
+        self.device = device          # the model's load_device in a one-rank-per-GPU job (None: the current device)
+
     def upscale(self, samples, upscale_method, width, height, crop="disabled"):
         if width == 0 and height == 0:
             return (samples,)
         s = samples.copy()
-        s["samples"] = bislerp(samples["samples"], max(64, width) // 8, max(64, height) // 8)   # the only mode (LD.py:521-523)
+        s["samples"] = bislerp(samples["samples"], max(64, width) // 8, max(64, height) // 8, device=self.device)   # the only mode (LD.py:521-523)
         return (s,)
 
 
@@ -197,7 +201,7 @@ def txt2img(model, clip, vae, prompt_tokens, negative_tokens, width=512, height=
     lat = EmptyLatentImage().generate(width, height, batch_size)[0]
     lat = KSampler2().sample(model, seed, steps, cfg, sampler_name, scheduler, pos, neg, lat)[0]
     if hires:   # hires-fix (LD.py:10585-10603): bislerp x2, then 10 Euler-a steps at denoise 0.45, cfg 8
-        lat = LatentUpscale().upscale(lat, "bislerp", width * 2, height * 2)[0]
+        lat = LatentUpscale(model.load_device).upscale(lat, "bislerp", width * 2, height * 2)[0]
         lat = KSampler2().sample(model, seed, 10, 8, "euler_ancestral", "normal", pos, neg, lat, denoise=0.45)[0]
     return VAEDecode().decode(vae, lat)[0]
 

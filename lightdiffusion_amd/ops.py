@@ -30,10 +30,16 @@ _WS = {}
 
 
 def _ws(nbytes: int, device) -> torch.Tensor:
-    """Per-device scratch for split-K partials / GEGLU repack, grown on demand and reused: the operator seam is also the CLIP
-    path (60+ calls per prompt), so no per-call allocation.  Stream-ordered reuse is safe: every op that takes it runs on
-    the current stream and is done with it when the next one starts."""
-    key = (torch.device(device).type, torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device())
+    """Scratch for split-K partials / GEGLU repack / LN-fold temporaries, cached per (device, stream) and grown on demand: the
+    operator seam is also the CLIP path (60+ calls per prompt), so no per-call allocation.  Reuse is stream-ordered — every op
+    that takes the buffer runs on the stream the buffer is keyed by and is done with it when the next one starts — so ops
+    issued on two streams never share slabs.  Under hipGraph capture nothing is cached: a buffer first grown there would live in
+    the graph's private pool (and a cached pointer baked into a graph would race with eager ops), so capture allocates per call."""
+    d = torch.device(device)
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)

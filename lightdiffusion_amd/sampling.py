@@ -293,12 +293,20 @@ def _cat_ctx(ctx_list: List[torch.Tensor]) -> torch.Tensor:
 
 def sampling_function(model, x, timestep, uncond, cond, cond_scale, model_options=None, seed=None):
     """sampling_function / calc_cond_batch / cfg_function (LD.py:2492-2626): ONE batched UNet call in the order
-    [uncond, cond] (the reference reverses its to-run list, LD.py:2515), then uncond + (cond - uncond) * scale."""
+    [uncond, cond] (the reference reverses its to-run list, LD.py:2515), then uncond + (cond - uncond) * scale.
+
+    Several entries in a conditioning list: the reference runs every entry over the WHOLE latent with weight 1 and averages
+    them per list — its `get_area_and_mult` (LD.py:2435-2458) hard-codes area = the full latent and strength = 1.0 and never
+    looks at "area", "strength", "mask" or timestep-range keys, so neither does this mirror (same images as the reference;
+    those keys are inert there).  That case takes one eager UNet call on (len(uncond) + len(cond)) * B samples; the single-entry
+    case — every call the reference's own pipelines make — replays the captured hipGraph."""
     model_options = model_options or {}
     b = x.shape[0]
+    if not cond or not uncond:
+        raise ValueError("sampling_function needs at least one positive and one negative conditioning entry")
 
     def ctx_of(c):
-        t = c[0]["cross_attn"]
+        t = c["cross_attn"]
         if t.shape[0] != b:
             if t.shape[0] != 1:
                 raise RuntimeError(f"conditioning batch {t.shape[0]} does not match latent batch {b}")
@@ -306,25 +314,35 @@ def sampling_function(model, x, timestep, uncond, cond, cond_scale, model_option
         return t
 
     # the batched context is step-invariant: build it once per run (cache lives in the guider's per-run model_options) and
-    # tag it with a token that is never reused, so the UNet wrapper re-projects K / V^T exactly once per run
+    # tag it with a token that is never reused, so the UNet wrapper re-projects K / V^T exactly once per run.
+    # Batch order = the reference's: its to-run list [cond.., uncond..] is consumed from the back (LD.py:2505-2515).
+    n_u, n_c = len(uncond), len(cond)
     cache = model_options.setdefault("_ld_ctx_cache", {})
     key = (b, id(uncond), id(cond))
     if key not in cache:
         cache.clear()
-        cache[key] = (_cat_ctx([ctx_of(uncond), ctx_of(cond)]).contiguous(), next(_CTX_TOKENS))
+        cache[key] = (_cat_ctx([ctx_of(c) for c in reversed(uncond)] + [ctx_of(c) for c in reversed(cond)]).contiguous(), next(_CTX_TOKENS))
     ctx, token = cache[key]
     wrapper = model_options.get("model_function_wrapper")
-    if hasattr(wrapper, "cfg_denoise") and not model_options.get("ld_eager_unbatched", False):
+    single = n_u == 1 and n_c == 1
+    if single and hasattr(wrapper, "cfg_denoise") and not model_options.get("ld_eager_unbatched", False):
         # MI355X fast path: the whole guided step (cat, UNet on 2B samples, CFG mix) is one replayed hipGraph
         return wrapper.cfg_denoise(x, timestep, ctx, cond_scale, token=token, use_graph=model_options.get("ld_use_graph", True))
-    x2 = torch.cat([x, x])
-    s2 = torch.cat([timestep, timestep])
-    c = {"c_crossattn": ctx, "transformer_options": {"cond_or_uncond": [1, 0], "sigmas": timestep, "ld_ctx_token": token}}
+    chunks = n_u + n_c
+    xs = torch.cat([x] * chunks)
+    ss = torch.cat([timestep] * chunks)
+    cou = [1] * n_u + [0] * n_c
+    c = {"c_crossattn": ctx, "transformer_options": {"cond_or_uncond": cou, "sigmas": timestep, "ld_ctx_token": token}}
     if wrapper is not None:
-        out = wrapper(model.apply_model, {"input": x2, "timestep": s2, "c": c, "cond_or_uncond": [1, 0]})
+        out = wrapper(model.apply_model, {"input": xs, "timestep": ss, "c": c, "cond_or_uncond": cou})
     else:
-        out = model.apply_model(x2, s2, **c)
-    return ops.cfg_combine(out.contiguous(), cond_scale)
+        out = model.apply_model(xs, ss, **c)
+    if single:
+        return ops.cfg_combine(out.contiguous(), cond_scale)
+    parts = out.chunk(chunks)                      # out_conds[i] = sum(output * 1) / count  (LD.py:2569-2591)
+    uncond_pred = torch.stack(parts[:n_u]).sum(0) / float(n_u)
+    cond_pred = torch.stack(parts[n_u:]).sum(0) / float(n_c)
+    return uncond_pred + (cond_pred - uncond_pred) * cond_scale
 
 
 class KSAMPLER:

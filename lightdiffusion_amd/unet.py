@@ -50,6 +50,16 @@ def _load_params(handle, count_fn, info_fn, load_fn, src: WeightSource, device, 
     torch.cuda.synchronize(device)
 
 
+def _parse_launches(fn, handle) -> list:
+    buf = C.create_string_buffer(1 << 18)
+    check(fn(handle, buf, len(buf)), "profile_launches")
+    out = []
+    for line in buf.value.decode().splitlines():
+        what, a, b, c, d, fl, us, kern = line.split("\t")
+        out.append((what, (int(a), int(b), int(c), int(d)), float(fl), float(us), kern))
+    return out
+
+
 class MI355XUNet:
     """SD1.x UNet resident on one MI355X.  `cfg` as in `weights.sd15_unet_config()`."""
 
@@ -176,6 +186,10 @@ class MI355XUNet:
             out[name] = (float(ms), float(fl), int(n))
         return out
 
+    def profile_launches(self) -> list:
+        """Per launch of the last `profile()` call: [(what, (a, b, c, d), flops, microseconds, kernel)] in launch order."""
+        return _parse_launches(lib().ld_unet_profile_launches, self._h)
+
     # -- the reference's plugin seam
     def _sync_context(self, ctx: torch.Tensor, n: int, h: int, w: int, token=None) -> None:
         """Make the resident cross-attention K / V^T those of `ctx`.  The reference re-concatenates the context every step
@@ -284,6 +298,16 @@ class MI355XVAE:
         with torch.cuda.device(self.device):
             check(lib().ld_vae_decode(self._h, z.data_ptr(), out.data_ptr(), b, h, w, _stream()), "ld_vae_decode")
         return out
+
+    def profile_decode(self, z: torch.Tensor) -> list:
+        """One decode with HIP events around every launch -> [(what, dims, flops, microseconds, kernel)] in launch order."""
+        z = z.to(self.device, torch.float32).contiguous()
+        b, _, h, w = z.shape
+        self._ensure(b, h, w)
+        out = torch.empty(b, 8 * h, 8 * w, self.cfg["out_ch"], dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().ld_vae_profile(self._h, z.data_ptr(), out.data_ptr(), b, h, w, _stream()), "ld_vae_profile")
+        return _parse_launches(lib().ld_vae_profile_launches, self._h)
 
     def decode(self, samples_in: torch.Tensor) -> torch.Tensor:
         """VAE.decode (LD.py:6357-6381): returns [B, 8h, 8w, 3] fp32 in [0,1] on the CPU (`intermediate_device`)."""

@@ -62,6 +62,8 @@ _DEFS = {
     "CLIPAttention", "CLIPMLP", "CLIPLayer", "CLIPEncoder", "CLIPEmbeddings", "CLIPTextModel_", "CLIPTextModel",
     # prompt weighting parser (LD.py:4733-4793)
     "parse_parentheses", "token_weights", "escape_important", "unescape_important", "SDTokenizer",
+    # token-weight encoder around the text model (LD.py:4526-4730): the e2e goldens start from token ids
+    "gen_empty_tokens", "ClipTokenWeightEncoder", "SDClipModel",
     # UNet (LD.py:5083-5767)
     "forward_timestep_embed1", "Upsample1", "Downsample1", "ResBlock1", "apply_control1", "UNetModel1",
     # model wrappers (LD.py:5779-5976)
@@ -130,7 +132,7 @@ def load_reference(path: str = REF_PATH) -> types.SimpleNamespace:
         "load_models_gpu": lambda *a, **k: None, "get_free_memory": lambda *a, **k: 1 << 50,
         "dtype_size": lambda dtype: torch.empty((), dtype=dtype).element_size(),
         "taesd_preview": lambda x: None,
-        "copy": __import__("copy"), "uuid": __import__("uuid"),
+        "copy": __import__("copy"), "uuid": __import__("uuid"), "json": __import__("json"),
         "isfunction": __import__("inspect").isfunction,
         "CLIPTokenizer": None,      # default argument of SDTokenizer.__init__; goldens inject their own word tokenizer
         "optimized_attention_for_device": lambda device, mask=False, small_input=False: ns["attention_pytorch"],

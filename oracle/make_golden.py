@@ -18,7 +18,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lightdiffusion_amd import weights as W          # noqa: E402
-from oracle.extract_ref import load_reference         # noqa: E402
+from oracle.extract_ref import REF_PATH, load_reference         # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -402,6 +402,170 @@ def g_lora():
     with open(os.path.join(OUT, "unet_to_diffusers.json"), "w") as f:
         json.dump({k: dict(sorted(v.items())) for k, v in maps.items()}, f)
     print("wrote unet_to_diffusers.json", {k: len(v) for k, v in maps.items()})
+
+
+# ------------------------------------------------------------------ 10. full-length, full-size end-to-end runs (configs #2 / #3 / #5)
+E2E_POS = [(49406, 1.0), (1125, 1.0), (2368, 1.0), (539, 1.3), (320, 1.3), (2242, 1.0), (267, 1.0), (4917, 0.8), (7857, 1.0),
+           (3878, 1.0), (267, 1.0), (12609, 1.1), (2870, 1.1)] + [(49407, 1.0)] * 64
+E2E_NEG = [(49406, 1.0)] + [(49407, 1.0)] * 76
+
+
+class _StepRecorder:
+    """A `model_function_wrapper` (LD.py:2558-2567) that passes straight through to the reference's apply_model and keeps
+    the latent every sampler step starts from (row 0 of the [uncond, cond] batch, every second pixel)."""
+
+    def __init__(self):
+        self.xs = []
+
+    def __call__(self, apply_model, params):
+        self.xs.append(params["input"][0:1, :, ::2, ::2].clone())
+        return apply_model(params["input"], params["timestep"], **params["c"])
+
+    def to(self, device):
+        return self
+
+
+def _ref_decoder():
+    vcfg = W.sd15_vae_config()
+    dec = ref.Decoder(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=vcfg["ch"],
+                      ch_mult=vcfg["ch_mult"], num_res_blocks=vcfg["num_res_blocks"], attn_resolutions=[], dropout=0.0)
+    eng = ref.AutoencodingEngine(None, dec, None)
+    sd = eng.state_dict()
+    eng.load_state_dict({k: W.synth_tensor(k, tuple(v.shape)) for k, v in sd.items() if not k.startswith("quant_conv")}, strict=False)
+    return lambda z: torch.clamp((eng.decode(z) + 1.0) / 2.0, 0.0, 1.0).movedim(1, -1)      # VAE.decode LD.py:6357-6381
+
+
+def _img_fields(tag, img, sub):
+    c0 = img.shape[1] // 2 - 37
+    return {f"{tag}img_sub": img[:, ::sub, ::sub], f"{tag}crop": img[:, c0:c0 + 96, c0:c0 + 96], f"{tag}crop_at": np.array([c0, c0]),
+            f"{tag}img_mean": img.mean(), f"{tag}img_std": img.std(),
+            f"{tag}img_saturated": ((img <= 0.0) | (img >= 1.0)).float().mean()}
+
+
+def g_e2e(cfg_scales=(None,)):
+    """The reference's own call stack, fp32 on the CPU, SD1.5-size synthetic net, full step counts:
+    token ids -> SDClipModel.encode_token_weights (clip skip -2) -> common_ksampler / sample -> Decoder.
+      cfg2: B=1, 20 steps dpmpp_2m_sde eta=0 ("DPM++ 2M") / karras, cfg 7        (BASELINE config #2; #1 is this very run)
+      cfg3: B=2, 30 steps euler_ancestral / normal, cfg 7, host-generator noise   (config #3)
+      cfg5: cfg2's latent -> bislerp x2 -> 10 euler_ancestral steps at denoise 0.45, cfg 8 -> 1024^2 decode   (config #5)
+    `anchor`: cfg2 once more with every UNet weight rounded to fp16 (what the reference's own unet_dtype1 stores,
+    LD.py:6418-6423) — the drift of the REFERENCE against itself under fp16 weight storage, the yardstick for the HIP path.
+    ≈ 12 min on 8 cores.  `python oracle/make_golden.py e2e` writes the cfg-7/8 files; `e2e_cfg1` the same runs at cfg 1."""
+    import time
+    t0 = time.time()
+    suffix = "" if cfg_scales[0] is None else "_cfg1"
+    cpu = torch.device("cpu")
+    # ---- conditioning from token ids through the reference's token-weight encoder
+    clip = ref.SDClipModel(device="cpu", dtype=torch.float32, layer="last",
+                           textmodel_json_config=os.path.join(os.path.dirname(REF_PATH), "_internal", "clip", "sd1_clip_config.json"))
+    tsd = clip.transformer.state_dict()
+    clip.transformer.load_state_dict({k: W.synth_tensor(k, tuple(v.shape)) for k, v in tsd.items() if k != "text_projection.weight"},
+                                     strict=False)
+    clip.reset_clip_options()
+    clip.set_clip_options({"layer": -2})                       # CLIPSetLastLayer(-2), LD.py:6604-6608 / 10016
+    cpos, ppos = clip.encode_token_weights([E2E_POS])
+    cneg, pneg = clip.encode_token_weights([E2E_NEG])
+    del clip
+    if not suffix:
+        save("e2e_cond", pos_ids=np.array([t for t, _ in E2E_POS]), pos_w=np.array([w for _, w in E2E_POS], dtype=np.float32),
+             neg_ids=np.array([t for t, _ in E2E_NEG]), cond_pos=cpos, cond_neg=cneg, pooled_pos=ppos)
+    pos, neg = [[cpos, {"pooled_output": ppos}]], [[cneg, {"pooled_output": pneg}]]
+    print(f"[e2e] clip done {time.time() - t0:.0f}s", flush=True)
+
+    model, patcher = build_ref_model(W.sd15_unet_config())
+    decode = _ref_decoder()
+
+    def never(s, sn):
+        raise AssertionError("noise sampler called with eta=0")
+
+    def run_cfg2(p, scale):
+        rec = _StepRecorder()
+        p = p.clone()
+        p.set_model_unet_function_wrapper(rec)
+        lat = ref.EmptyLatentImage().generate(512, 512, 1)[0]["samples"]
+        sig = ref.calculate_sigmas(model.model_sampling, "karras", 20)
+        noise = ref.prepare_noise(lat, 2002)
+        out = ref.sample(p, noise, pos, neg, scale, cpu, ref.ksampler("dpmpp_2m_sde", {"eta": 0.0, "noise_sampler": never}), sig,
+                         p.model_options, latent_image=lat, seed=2002)
+        return out, torch.cat(rec.xs)
+
+    s7 = 7.0 if cfg_scales[0] is None else cfg_scales[0]
+    s8 = 8.0 if cfg_scales[0] is None else cfg_scales[0]
+    lat2, traj2 = run_cfg2(patcher, s7)
+    img2 = decode(lat2)
+    print(f"[e2e] cfg2 done {time.time() - t0:.0f}s  |lat| {float(lat2.abs().mean()):.3f}", flush=True)
+
+    # ---- cfg3
+    rec = _StepRecorder()
+    p3 = patcher.clone()
+    p3.set_model_unet_function_wrapper(rec)
+    lat = ref.EmptyLatentImage().generate(512, 512, 2)[0]
+    # the reference never repeats a conditioning to the latent batch (repeat_to_batch_size is the identity, LD.py:397-398):
+    # a batch of 2 needs batch-2 conditionings
+    pos_b = [[cpos.repeat(2, 1, 1), {"pooled_output": ppos}]]
+    neg_b = [[cneg.repeat(2, 1, 1), {"pooled_output": pneg}]]
+    lat3 = ref.common_ksampler(p3, 3003, 30, s7, "euler_ancestral", "normal", pos_b, neg_b, lat, denoise=1.0)[0]["samples"]
+    traj3 = torch.cat(rec.xs)
+    img3 = decode(lat3)
+    f3 = {}
+    f3.update(_img_fields("r0_", img3[0:1], 4))
+    f3.update(_img_fields("r1_", img3[1:2], 4))
+    save("e2e_cfg3" + suffix, latent=lat3, traj_sub=traj3, cfg=np.array(s7), seed=np.array(3003), **f3)
+    print(f"[e2e] cfg3 done {time.time() - t0:.0f}s", flush=True)
+
+    # ---- cfg5 (hires-fix of cfg2's result, LD.py:10585-10603)
+    rec = _StepRecorder()
+    p5 = patcher.clone()
+    p5.set_model_unet_function_wrapper(rec)
+    up = ref.LatentUpscale().upscale({"samples": lat2}, "bislerp", 1024, 1024, "disabled")[0]
+    lat5 = ref.common_ksampler(p5, 5005, 10, s8, "euler_ancestral", "normal", pos, neg, up, denoise=0.45)[0]["samples"]
+    traj5 = torch.cat(rec.xs)
+    img5 = decode(lat5)
+    save("e2e_cfg5" + suffix, upscaled=up["samples"], latent=lat5, traj_sub=traj5, cfg=np.array(s8), seed=np.array(5005),
+         **_img_fields("", img5, 8))
+    print(f"[e2e] cfg5 done {time.time() - t0:.0f}s", flush=True)
+
+    # ---- anchor: the reference against itself with fp16-stored UNet weights
+    for prm in model.diffusion_model.parameters():
+        prm.data = prm.data.half().float()
+    lat2h, traj2h = run_cfg2(patcher, s7)
+    img2h = decode(lat2h)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    anchor_curve = np.array([rel(traj2h[i], traj2[i]) for i in range(traj2.shape[0])])
+    save("e2e_cfg2" + suffix, latent=lat2, traj_sub=traj2, cfg=np.array(s7), seed=np.array(2002),
+         anchor_traj_rel=anchor_curve, anchor_latent_rel=np.array(rel(lat2h, lat2)),
+         anchor_img_maxabs=(img2h - img2).abs().max(), anchor_img_meanabs=(img2h - img2).abs().mean(),
+         **_img_fields("", img2, 4))
+    print(f"[e2e] anchor done {time.time() - t0:.0f}s  latent rel {rel(lat2h, lat2):.3e}  img max {float((img2h - img2).abs().max()) * 255:.2f}/255 "
+          f"mean {float((img2h - img2).abs().mean()) * 255:.3f}/255", flush=True)
+    print("[e2e] anchor curve", np.array2string(anchor_curve, precision=2), flush=True)
+
+
+def g_e2e_cfg1():
+    g_e2e((1.0,))
+
+
+# ------------------------------------------------------------------ 11. several conditioning entries per list (calc_cond_batch averaging, LD.py:2492-2591)
+def g_multicond():
+    """Two positive entries (the second carrying the keys the reference's stripped get_area_and_mult ignores: area / strength)
+    and two negative ones of different token counts (77 / 154: CONDCrossAttn.concat pads by repetition), Euler-a on the tiny UNet."""
+    cfg = W.tiny_unet_config()
+    model, patcher = build_ref_model(cfg)
+    d = cfg["context_dim"]
+    pos = [[rnd((2, 77, d), 141), {"pooled_output": None}],           # batch-sized: the reference never repeats a conditioning (LD.py:397-398)
+           [rnd((2, 77, d), 142), {"pooled_output": None, "area": (4, 4, 0, 0), "strength": 0.3}]]
+    neg = [[rnd((2, 77, d), 143), {"pooled_output": None}], [rnd((2, 154, d), 144), {"pooled_output": None}]]
+    lat = ref.EmptyLatentImage().generate(128, 96, 2)[0]
+    seen = {}
+    def hook(apply_model, params):
+        if not seen:
+            seen.update(cond_or_uncond=np.array(params["cond_or_uncond"]), ctx=params["c"]["c_crossattn"].clone())
+        return apply_model(params["input"], params["timestep"], **params["c"])
+    p2 = patcher.clone()
+    p2.set_model_unet_function_wrapper(hook)
+    r = ref.common_ksampler(p2, 4321, 5, 6.0, "euler_ancestral", "normal", pos, neg, lat, denoise=1.0)
+    save("multicond", pos0=pos[0][0], pos1=pos[1][0], neg0=neg[0][0], neg1=neg[1][0], out=r[0]["samples"],
+         hook_cond_or_uncond=seen["cond_or_uncond"], hook_ctx=seen["ctx"])
 
 
 if __name__ == "__main__":

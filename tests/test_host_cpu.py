@@ -171,13 +171,13 @@ def _run_sharded(global_batch):
                                  global_batch=global_batch, seed=321, steps=5, run_sampler=run_sampler)
 
 
-def _sharded_worker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, global_batch=5):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import torch.distributed as dist
     from lightdiffusion_amd import dist as D
     D.init("gloo")
     torch.manual_seed(1000 + rank)           # ranks start from different global-generator states: the entry must not depend on them
-    out = _run_sharded(5)
+    out = _run_sharded(global_batch)
     q.put((rank, None if out is None else out.clone()))
     dist.barrier()
     dist.destroy_process_group()
@@ -261,3 +261,131 @@ def test_lora_key_maps_and_merge_match_reference():
     want = {"model." + str(k) for k in g["patched_unet_keys"]}
     km = CK.lora_key_map(sd)
     assert {km[m] for m in {k[:-len(".lora_up.weight")] for k in lora if k.endswith(".lora_up.weight")} if m in km and km[m].startswith(P)} == want
+
+
+def test_txt2img_sharded_world_3_uneven_batch_8():
+    """global batch 8 over 3 ranks (3 + 3 + 2): the padded all-gather path of `gather_images` and uneven row blocks."""
+    single = _run_sharded(8)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 271) % 500
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 3, port, q, 8)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res[1] is None and res[2] is None and torch.equal(res[0], single)
+    from lightdiffusion_amd import dist as D
+    assert [(D.shard_rows(8, r, 3).start, D.shard_rows(8, r, 3).stop) for r in range(3)] == [(0, 3), (3, 6), (6, 8)]
+    assert [D.shard_rows(2, r, 3).stop - D.shard_rows(2, r, 3).start for r in range(3)] == [1, 1, 0]      # a rank may own nothing
+
+
+def test_bench_spawn_ranks_environment(monkeypatch):
+    """`bench.py --gpus N` without a torchrun environment: N children, each with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    rendezvous on 127.0.0.1, dmabuf IPC kept; the parent never imports torch (it must not touch the GPU before its ranks do)."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("ld_bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    started = []
+
+    class FakeProc:
+        def __init__(self, argv, env):
+            started.append((argv, env))
+
+        def wait(self):
+            return 0
+
+    import types
+    monkeypatch.setattr(bench, "subprocess", types.SimpleNamespace(Popen=lambda argv, env=None: FakeProc(argv, env)))
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(3, ["--gpus", "3", "--steps", "5"])
+    assert e.value.code == 0 and len(started) == 3
+    ports = set()
+    for r, (argv, env) in enumerate(started):
+        assert argv[0] == sys.executable and argv[1].endswith("bench.py") and argv[2:] == ["--gpus", "3", "--steps", "5"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"]) == (str(r), str(r), "3", "127.0.0.1")
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        ports.add(env["MASTER_PORT"])
+    assert len(ports) == 1
+    # the parent process of a --gpus N run imports no torch before it spawns (checked in a clean interpreter)
+    code = ("import sys, runpy\nsys.argv = ['bench.py', '--gpus', '2']\nimport subprocess\n"
+            "class P:\n    def __init__(self, *a, **k): assert 'torch' not in sys.modules, 'torch imported before spawn'\n"
+            "    def wait(self): return 0\n"
+            "subprocess.Popen = P\n"
+            "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n    assert e.code == 0, e.code\n"
+            "assert 'torch' not in sys.modules\nprint('parent-clean')\n" % os.path.join(ROOT, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=60)
+    assert out.returncode == 0 and "parent-clean" in out.stdout, out.stderr
+
+
+class _StubApply:
+    def apply_model(self, *a, **k):
+        raise AssertionError("the wrapper hook must be used")
+
+
+def test_sampling_function_averages_multiple_conds():
+    """calc_cond_batch with several entries per list (LD.py:2492-2591): one UNet call over (n_uncond + n_cond) * B samples in the
+    reference's batch order, per-list average, then CFG; `area` / `strength` keys are inert (the reference's get_area_and_mult
+    hard-codes the whole latent and weight 1, LD.py:2435-2458)."""
+    from lightdiffusion_amd import sampling as S
+    b, d = 2, 8
+    calls = []
+
+    def wrapper(apply_model, params):
+        calls.append(params)
+        ctx = params["c"]["c_crossattn"]
+        return params["input"] * 0.5 + ctx.mean(dim=(1, 2)).view(-1, 1, 1, 1)
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(b, 4, 6, 5, generator=g)
+    mk = lambda t, **kw: dict(kw, cross_attn=torch.randn(b, t, d, generator=g))
+    pos = [mk(77), mk(77, area=(2, 2, 0, 0), strength=0.3)]
+    neg = [mk(77), mk(154)]
+    out = S.sampling_function(_StubApply(), x, torch.full((b,), 2.0), neg, pos, 6.0, {"model_function_wrapper": wrapper})
+    assert len(calls) == 1 and calls[0]["cond_or_uncond"] == [1, 1, 0, 0] and calls[0]["input"].shape[0] == 4 * b
+    ctx = calls[0]["c"]["c_crossattn"]
+    assert ctx.shape == (4 * b, 154, d)
+    assert torch.equal(ctx[:b], neg[1]["cross_attn"]) and torch.equal(ctx[b:2 * b], neg[0]["cross_attn"].repeat(1, 2, 1))
+    assert torch.equal(ctx[2 * b:3 * b], pos[1]["cross_attn"].repeat(1, 2, 1)) and torch.equal(ctx[3 * b:], pos[0]["cross_attn"].repeat(1, 2, 1))
+    m = lambda c: c["cross_attn"].mean(dim=(1, 2)).view(-1, 1, 1, 1)
+    u = x * 0.5 + (m(neg[0]) + m(neg[1])) / 2
+    c = x * 0.5 + (m(pos[0]) + m(pos[1])) / 2
+    assert torch.allclose(out, u + (c - u) * 6.0, atol=1e-5)
+    with pytest.raises(ValueError):
+        S.sampling_function(_StubApply(), x, torch.full((b,), 2.0), [], pos, 6.0, {"model_function_wrapper": wrapper})
+    with pytest.raises(RuntimeError):
+        S.sampling_function(_StubApply(), x, torch.full((b,), 2.0), [dict(cross_attn=torch.zeros(3, 77, d))], pos, 6.0, {"model_function_wrapper": wrapper})
+
+
+def test_lora_alias_patches_a_weight_once():
+    """A file that names one weight through two aliases patches it once — the reference keys its patch dict by TARGET weight
+    (LD.py:549-575); a module with lora_up but no lora_down is reported as such, not as 'matches no layer'."""
+    import warnings
+    from lightdiffusion_amd import checkpoint as CK
+    sd, ucfg, _, _ = _synthetic_checkpoint()
+    key = "model.diffusion_model.input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight"
+    sd[key] = sd[key].float()
+    before = sd[key].clone()
+    g = torch.Generator().manual_seed(9)
+    up, down = torch.randn(64, 4, generator=g), torch.randn(4, 64, generator=g)
+    up2, down2 = torch.randn(64, 4, generator=g), torch.randn(4, 64, generator=g)
+    ldm = "lora_unet_input_blocks_1_1_transformer_blocks_0_attn1_to_q"
+    dif = "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q"
+    km = CK.lora_key_map(sd)
+    assert km[ldm] == km[dif] == key
+    lora = {ldm + ".lora_up.weight": up, ldm + ".lora_down.weight": down, dif + ".lora_up.weight": up2, dif + ".lora_down.weight": down2,
+            "lora_unet_input_blocks_1_1_transformer_blocks_0_attn1_to_k.lora_up.weight": up}
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        res = CK.merge_lora(sd, lora, 1.0)
+    assert res == 1 and res.unet == 1 and res.unmatched == ()
+    assert res.missing_down == ("lora_unet_input_blocks_1_1_transformer_blocks_0_attn1_to_k",)
+    assert any("no lora_down" in str(w.message) for w in wl)
+    winner = [n for n in km if km[n] == key and n in (ldm, dif)][-1]            # last alias in key-map order wins
+    u, dn = (up, down) if winner == ldm else (up2, down2)
+    assert torch.allclose(sd[key], before + u @ dn, atol=1e-5)

@@ -141,3 +141,31 @@ def test_checkpoint_loader_roundtrip(stack, tmp_path):
     assert torch.equal(ya, yb)
     z = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(3))
     assert torch.equal(vae.decode(z), stack[2].decode(z))
+
+
+def test_multiple_conds_per_list_match_reference(stack):
+    """Two positive and two negative entries (77 / 154 tokens; `area` / `strength` keys the reference's stripped
+    get_area_and_mult ignores): per-list average of whole-latent predictions (calc_cond_batch, LD.py:2492-2591), 5 Euler-a
+    steps on the tiny UNet against the reference's common_ksampler; the batch the hook sees is the reference's, row for row."""
+    from lightdiffusion_amd import nodes
+    model = stack[0]
+    g = load_golden("multicond")
+    pos = [[g["pos0"], {"pooled_output": None}], [g["pos1"], {"pooled_output": None, "area": (4, 4, 0, 0), "strength": 0.3}]]
+    neg = [[g["neg0"], {"pooled_output": None}], [g["neg1"], {"pooled_output": None}]]
+    seen = {}
+    unet = model.model.diffusion_model
+
+    class Hook:
+        def __call__(self, apply_model, params):
+            if not seen:
+                seen.update(cou=list(params["cond_or_uncond"]), ctx=params["c"]["c_crossattn"].detach().cpu().clone())
+            return unet(apply_model, params)
+
+    m2 = model.clone()
+    m2.set_model_unet_function_wrapper(Hook())
+    lat = nodes.EmptyLatentImage().generate(128, 96, 2)[0]
+    out = nodes.KSampler2().sample(m2, 4321, 5, 6.0, "euler_ancestral", "normal", pos, neg, lat)[0]["samples"]
+    assert seen["cou"] == g["hook_cond_or_uncond"].tolist() and torch.equal(seen["ctx"], g["hook_ctx"])
+    assert rel_l2(out, g["out"]) < TRAJ_TOL
+    out2 = nodes.KSampler2().sample(model, 4321, 5, 6.0, "euler_ancestral", "normal", pos, neg, lat)[0]["samples"]   # wrapper = the UNet itself
+    assert torch.equal(out, out2)

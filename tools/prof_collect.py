@@ -20,9 +20,10 @@ def short_name(k):
     m = re.match(r"gemm5_kernel<(true|false)(?:, \d+)?>", k)
     if m:
         return f"gemm5_kernel<256,320,{'conv' if m.group(1) == 'true' else 'plain'}>"
-    m = re.match(r"conv6_kernel<(\d+), (true|false)>", k)
+    m = re.match(r"conv6_kernel<(\d+), (true|false)(?:, (\d+))?(?:, (true|false))?>", k)
     if m:
-        return f"conv6_kernel<W{m.group(1)},{'halo+groupnorm' if m.group(2) == 'true' else 'halo'}>"
+        return f"conv6_kernel<W{m.group(1)},{'halo+groupnorm' if m.group(2) == 'true' else 'halo'}" + (f",{m.group(3)}" if m.group(3) and m.group(3) != "320" else "") + \
+               (",up" if m.group(4) == "true" else "") + ">"
     m = re.match(r"gemm7_kernel<(true|false)(?:, (?:true|false))?>", k)
     if m:
         return f"gemm7_kernel<256,K320,{'geglu' if m.group(1) == 'true' else 'plain'}>"
@@ -62,6 +63,11 @@ def main():
     tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     db = json.load(open(tp)) if os.path.exists(tp) else {}
     t = db[tag] = {}   # a pass replaces the tag: kernel names change between rounds
+    # provenance: the library the passes ran (bench.py only reports `traffic` when this matches the library it loads)
+    import hashlib
+    lib = os.environ.get("LD_MI355X_LIB") or os.path.join(ROOT, "lightdiffusion_amd", "libld_mi355x.so")
+    t["_lib"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+    t["_driver"] = os.environ.get("LD_PROF_DRIVER", "bench.py")
     for k in acc:
         e = {}
         if "FETCH_SIZE" in acc[k]:
