@@ -1154,10 +1154,11 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
 // wave): wave tile 64 x WN, WN = 16 TN.  Convolutions carry no LayerNorm fold and no
 // GEGLU, so this is the plain epilogue only (bias / bias_m / row vector / SiLU / residual), written once for every WN: two 16-row strips
 // at a time through the wave's slice of the (quiet) LDS, operands of a strip requested as one batch, predicated stores.
-template <int TN>
-__device__ __forceinline__ void v6_finish(const GemmParams& p, f32x4 (&acc)[4][TN], char* smem5, int m0, int n0, int wm0, int wn0, int wid, int lane, int ks,
+template <int TM, int TN>
+__device__ __forceinline__ void v6_finish(const GemmParams& p, f32x4 (&acc)[TM][TN], char* smem5, int m0, int n0, int wm0, int wn0, int wid, int lane, int ks,
                                           int splitk) {
-    constexpr int TM = 4, WN = TN * 16, LD = WN + 4, STRIP_BYTES = 16 * LD * 2;
+    static_assert(TM == 4 || TM == 8, "wave tile of 64 or 128 rows");
+    constexpr int WN = TN * 16, LD = WN + 4, STRIP_BYTES = 16 * LD * 2;
     constexpr int CPR = WN / 8, TOT = 16 * CPR, ITS = (TOT + 63) / 64;
     const int fr = lane & 15, fq = lane >> 4;
     const int m_w = m0 + wm0, n_w = n0 + wn0;
@@ -1225,20 +1226,23 @@ __device__ __forceinline__ void v6_finish(const GemmParams& p, f32x4 (&acc)[4][T
         }
     };
     half_t* Cs1 = Cs0 + 16 * LD;
-    stage(std::integral_constant<int, 0>{}, Cs0);
-    stage(std::integral_constant<int, 1>{}, Cs1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: the strips are complete
-    __builtin_amdgcn_sched_barrier(0);
-    strip(Cs0, m_w);
-    strip(Cs1, m_w + 16);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // strips consumed before the next pair overwrites them
-    __builtin_amdgcn_sched_barrier(0);
-    stage(std::integral_constant<int, 2>{}, Cs0);
-    stage(std::integral_constant<int, 3>{}, Cs1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    strip(Cs0, m_w + 32);
-    strip(Cs1, m_w + 48);
+    auto pair = [&](auto P) {                                            // strips 2P, 2P + 1 (literal indices: the accumulators stay in registers)
+        constexpr int i0 = 2 * decltype(P)::value;
+        stage(std::integral_constant<int, i0>{}, Cs0);
+        stage(std::integral_constant<int, i0 + 1>{}, Cs1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: the strips are complete
+        __builtin_amdgcn_sched_barrier(0);
+        strip(Cs0, m_w + 16 * i0);
+        strip(Cs1, m_w + 16 * i0 + 16);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // strips consumed before the next pair overwrites them
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    pair(std::integral_constant<int, 0>{});
+    pair(std::integral_constant<int, 1>{});
+    if constexpr (TM == 8) {
+        pair(std::integral_constant<int, 2>{});
+        pair(std::integral_constant<int, 3>{});
+    }
 }
 
 template <bool CONV, int EPI>
@@ -1470,14 +1474,22 @@ __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
 // Requirements (gemm_launch): ksize 3, stride 1, pad 1, no resize, Wo == W in {16, 32, 64, 128}, Ho * Wo % 256 == 0,
 // C1 % 32 == 0, C2 % 32 == 0, N % 320 == 0; a split over K is a split over slabs.
 // =====================================================================================================================
-template <int W, bool GN, int BN = V5_BN>   // GN: GroupNorm (+SiLU) of the input fused into the halo (separate instantiation: the plain conv keeps its
-                                            // registers); BN: tile width 320 (the UNet's N = 320 k) or 256 (the VAE's N = 256 / 512)
+// Round 3: (i) the tile is W pixels wide but the IMAGE may be wider (W = 128 only: p.Wo = 256, 512, 1024 ... — a tile is then TR rows
+// of one 128-pixel column band; the VAE's 256- and 512-pixel-row stages), (ii) BM = 512 (four rows of a 128-pixel band, wave tile
+// 128 x BN/2) gives the N = 128 convolutions of the VAE's last level 32 MFMAs per phase instead of 16, (iii) UP: the input is the
+// nearest-2x upsampling of the source (Upsample / Upsample1, LD.py:3498-3511, 5114-5152): halo pixel (y, x) comes from source pixel
+// (y >> 1, x >> 1) — only the loader's address changes.
+template <int W, bool GN, int BN = V5_BN, int BM = V5_BM, bool UP = false>
+                                            // GN: GroupNorm (+SiLU) of the input fused into the halo (separate instantiation: the plain conv keeps its
+                                            // registers); BN: tile width 320 (the UNet's N = 320 k), 256 (the VAE's N = 256 / 512) or 128 (its N = 128)
 __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
-    constexpr int TM = 4, TN = BN / 32;
+    constexpr int TM = BM / 64, TN = BN / 32;
     static_assert(BN == 320 || BN == 256 || BN == 160 || BN == 128, "tile width");
+    static_assert(BM == 256 || (BM == 512 && W == 128), "tile height: 256 pixels, or four rows of a 128-pixel band");
     static_assert(!GN || BN == V5_BN, "the fused GroupNorm only pays where the output is one 320-column tile wide");
+    static_assert(!(GN && UP), "no caller");
     constexpr int BPIECES = BN / 16, NB_ALL = BPIECES / 8, NB_EXTRA = BPIECES % 8;   // B pieces of a step: NB_ALL per wave + one more for waves < NB_EXTRA
-    constexpr int TR = 256 / W, HW2 = W + 2, HP = (TR + 2) * HW2;      // tile rows, halo row pitch (pixels), halo pixels
+    constexpr int TR = BM / W, HW2 = W + 2, HP = (TR + 2) * HW2;       // tile rows, halo row pitch (pixels), halo pixels
     constexpr int NH = ((HP + 15) / 16 + 7) / 8;                      // halo LDS-DMA pieces per wave and slab (uniform: spare pieces copy zeros)
     constexpr int HBYTES = NH * 8 * 1024;                              // one halo buffer
     constexpr int BSTAGE = BN * 64, NSTB = 4;                          // B ring: 4 stages of BN rows x 64 bytes
@@ -1498,23 +1510,27 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool grp1 = wid >= 4;
     const int wm = wid >> 1;
-    const int wm0 = wm * 64, wn0 = (wid & 1) * (BN / 2);
-    const int tiles_m = p.M / V5_BM, tiles_n = p.N / BN;
+    const int wm0 = wm * (BM / 4), wn0 = (wid & 1) * (BN / 2);
+    const int tiles_m = p.M / BM, tiles_n = p.N / BN;
     const int tiles = tiles_m * tiles_n;
     const int splitk = p.splitk > 1 ? p.splitk : 1;
     int bid = xcd_remap(blockIdx.x, tiles * splitk);
     const int ks = bid / tiles;
     bid -= ks * tiles;
     const int tn_i = bid % tiles_n, tm_i = bid / tiles_n;
-    const int m0 = tm_i * V5_BM, n0 = tn_i * BN;
+    const int n0 = tn_i * BN;
     const int Cin = p.C1 + p.C2;
     const int NS = Cin / 32;                                           // channel slabs
     const int s_begin = (int)((long long)ks * NS / splitk), s_end = (int)((long long)(ks + 1) * NS / splitk);
     const int nk = (s_end - s_begin) * 9;                              // 32-wide steps of this workgroup (>= 9)
 
     const half_t* zp = reinterpret_cast<const half_t*>(g_zero_row);
-    const int HWo = p.Ho * p.Wo;
-    const int img = m0 / HWo, row0 = (m0 - img * HWo) / W;             // this tile = image rows row0 .. row0 + TR - 1 of image img
+    // this tile = rows row0 .. row0 + TR - 1, columns col0 .. col0 + W - 1 of image img (W < 128: the image is W wide, col0 = 0)
+    const int Wimg = W == 128 ? p.Wo : W;
+    const int HWo = p.Ho * Wimg;
+    const int bands = Wimg / W, tiles_img = (p.Ho / TR) * bands;
+    const int img = tm_i / tiles_img, t_in = tm_i - img * tiles_img;
+    const int row0 = (t_in / bands) * TR, col0 = (t_in - (t_in / bands) * bands) * W;
 
     // ---- halo loader state: piece j of this wave covers halo pixels (wid + 8 j) * 16 .. + 15; lane -> (pixel, 16-byte chunk)
     int hpix[NH];                                                      // source pixel index inside the image, or -1 (border / spare)
@@ -1522,14 +1538,15 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     for (int j = 0; j < NH; ++j) {
         const int hp = (wid + 8 * j) * 16 + (lane >> 2);
         const int hy = hp / HW2, hx = hp - hy * HW2;
-        const int iy = row0 + hy - 1, ix = hx - 1;
-        hpix[j] = (hp < HP && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)W) ? iy * W + ix : -1;
+        const int iy = row0 + hy - 1, ix = col0 + hx - 1;
+        const bool in = hp < HP && (unsigned)iy < (unsigned)p.Ho && (unsigned)ix < (unsigned)Wimg;
+        hpix[j] = !in ? -1 : UP ? (iy >> 1) * (Wimg >> 1) + (ix >> 1) : iy * Wimg + ix;
     }
     const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)smem5);
     auto issue_halo = [&](int s, int buf) {                            // channel slab s (32 channels of the concatenated input) -> halo buffer buf
         const int c0 = s * 32;
         const bool second = c0 >= p.C1;
-        const half_t* src = (second ? p.A2 : p.A) + (long long)img * p.Hs * W * (second ? p.C2 : p.C1) + (second ? c0 - p.C1 : c0) + (lane & 3) * 8;
+        const half_t* src = (second ? p.A2 : p.A) + (long long)img * p.Hs * p.Ws * (second ? p.C2 : p.C1) + (second ? c0 - p.C1 : c0) + (lane & 3) * 8;
         const int Cs = second ? p.C2 : p.C1;
 #pragma unroll
         for (int j = 0; j < NH; ++j) {
@@ -1617,6 +1634,8 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     // ---- fragment read bases: A = halo pixel of output pixel (wm0 + 16 i + fr) at tap (0,0), B as v5
     const int fr = lane & 15, fq = lane >> 4;
     const int oyw = wm0 / W, oxw = wm0 - oyw * W;                      // first output pixel of this wave inside the tile
+    // the wave's BM / 4 output pixels are consecutive rows of the [M][N] output (one image row segment, or whole rows of a narrow image)
+    const int m0 = img * HWo + (row0 + oyw) * Wimg + col0 + oxw - wm0;   // so that m0 + wm0 is the wave's first output row
     const char* rdA = smem5 + ((oyw * HW2 + oxw + fr) * 64 + fq * 16);
     const unsigned rchunk = (unsigned)(fq ^ ((V5_SWZ >> (2 * ((fr >> 2) & 3))) & 3)) << 4;
     const char* rdB = smem5 + RING0 + (wn0 + fr) * 64 + rchunk;
@@ -1692,7 +1711,7 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     if (!grp1) __builtin_amdgcn_s_barrier();                            // group 0 waits out group 1's last MFMA phase
     if (GN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last ones retire before VALU reads the accumulators
     if constexpr (BN == V5_BN) v5_finish<0, false>(p, acc, smem5, nullptr, nullptr, 0, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
-    else v6_finish<TN>(p, acc, smem5, m0, n0, wm0, wn0, wid, lane, ks, splitk);
+    else v6_finish<TM, TN>(p, acc, smem5, m0, n0, wm0, wn0, wid, lane, ks, splitk);
 }
 
 // =====================================================================================================================
@@ -2314,32 +2333,50 @@ static bool v7_geglu_enabled() {
 #endif
 }
 
-// does this convolution run on the halo-tile kernel (v6), and with which split over K?
-static bool v6_plan(const GemmParams& p, int* sk_out, int* bn_out = nullptr) {
-    if (!(p.conv && p.ksize == 3 && p.stride == 1 && (p.pad < 0 || p.pad == 1) && p.Hv == p.Hs && p.Wv == p.Ws && p.Ho == p.Hs && p.Wo == p.Ws &&
-          (p.Wo == 16 || p.Wo == 32 || p.Wo == 64 || p.Wo == 128) && (p.Ho * p.Wo) % V5_BM == 0 && p.C1 % 32 == 0 && p.C2 % 32 == 0 &&
-          p.bm == 0 && p.bn == 0 && p.splitk == 0 && p.batch == 1 && p.act != 2 && p.M % V5_BM == 0))
+// does this convolution run on the halo-tile kernel (v6), and with which tile (rows x columns), split over K and loader (UP)?
+struct V6Plan {
+    int sk = 1, bn = 0, bm = V5_BM, wc = 0;   // wc: tile width in pixels (16 / 32 / 64 / 128; an image wider than 128 is cut into 128-pixel bands)
+    bool up = false;
+};
+static bool v6_plan(const GemmParams& p, V6Plan* out) {
+    const bool same = p.Hv == p.Hs && p.Wv == p.Ws;
+    const bool up = p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws;           // exact nearest 2x (Upsample: LD.py:3498-3511; Upsample1 when the skip is 2x)
+    if (!(p.conv && p.ksize == 3 && p.stride == 1 && (p.pad < 0 || p.pad == 1) && (same || up) && p.Ho == p.Hv && p.Wo == p.Wv &&
+          p.C1 % 32 == 0 && p.C2 % 32 == 0 && p.bm == 0 && p.bn == 0 && p.splitk == 0 && p.batch == 1 && p.act != 2))
         return false;
+    if (up && (p.C2 != 0 || p.gn_scale != nullptr)) return false;
+    const int wc = (p.Wo == 16 || p.Wo == 32 || p.Wo == 64 || p.Wo == 128) ? p.Wo : (p.Wo > 128 && p.Wo % 128 == 0) ? 128 : 0;
+    if (wc == 0) return false;
 #ifdef LD_AB_BUILD
     if (g_no_v5 & 2) return false;
+    if ((g_no_v5 & 256) && (up || p.Wo > 128)) return false;      // A/B: round-2 coverage only
 #endif
-    // tile width: 320 for the UNet's N = 320 k; 256 for the VAE's N = 256 / 512 at 64- and 128-pixel rows (VAE decode b=8 29.9 -> 28.8 ms).
+    // tile: 320 columns for the UNet's N = 320 k; 256 for the VAE's N = 256 / 512 at >= 64-pixel rows (VAE decode b=8 29.9 -> 28.8 ms);
+    // 512 pixels x 128 columns for its N = 128 (a 256 x 128 tile would leave a wave 16 MFMAs per phase: the step's fixed cost dominates).
     // (256 x 160 tiles for level 1 — 256 unsplit tiles instead of 128 + split — measured a net loss per launch inside the forward:
     // 16384 x 640 x 5760 737 vs 748 us per 6 launches, but 317 vs 291 / 217 vs 213 / 176 vs 170 us at K = 17280 / 11520 / 8640: a
     // 64 x 80 wave tile reads 1.3x the LDS bytes per MFMA and halves the MFMAs a step's fixed cost is spread over.)
-    int bn = 0;
-    const long long tm = p.M / V5_BM;
+    int bn = 0, bm = V5_BM;
     if (p.N % V5_BN == 0) {
         bn = V5_BN;
-    } else if (p.N % 256 == 0 && (p.Wo == 64 || p.Wo == 128) && p.gn_scale == nullptr
+    } else if (p.N % 256 == 0 && wc >= 64 && p.gn_scale == nullptr
 #ifdef LD_AB_BUILD
                && !(g_no_v5 & 64)
 #endif
     ) {
         bn = 256;
+    } else if (p.N % 128 == 0 && wc == 128 && p.gn_scale == nullptr
+#ifdef LD_AB_BUILD
+               && !(g_no_v5 & 256)
+#endif
+    ) {
+        bn = 128;
+        bm = 512;
     } else {
         return false;
     }
+    if (p.Ho % (bm / wc) != 0 || p.M % bm != 0) return false;       // whole tiles: bm / wc image rows each
+    const long long tm = p.M / bm;
     const long long t6 = tm * (p.N / bn);
     const int NS = (p.C1 + p.C2) / 32;
     int sk6 = 1;
@@ -2352,8 +2389,11 @@ static bool v6_plan(const GemmParams& p, int* sk_out, int* bn_out = nullptr) {
         if (sk6 > NS) sk6 = NS;
         while (sk6 > 1 && (size_t)sk6 * p.M * p.N * sizeof(float) > p.partial_bytes) --sk6;
     }
-    *sk_out = sk6;
-    if (bn_out != nullptr) *bn_out = bn;
+    out->sk = sk6;
+    out->bn = bn;
+    out->bm = bm;
+    out->wc = wc;
+    out->up = up;
     return t6 * sk6 >= 192;
 }
 
@@ -2364,9 +2404,8 @@ bool gemm_conv_fuses_groupnorm(const GemmParams& p) {
     // Measured (tools/gnconv_ab.py, same process): fused vs two-pass GroupNorm + the same halo conv: +4 % at N = 320 (level 0, one N
     // tile per M tile), +-0 % at N = 640, -3 % at N = 1280 — every N tile of an M tile normalises the same halo again, so the fusion
     // only pays where the output is one tile wide.
-    int sk = 0;
-    int bn = 0;
-    return p.N == V5_BN && v6_plan(p, &sk, &bn) && bn == V5_BN;
+    V6Plan pl;
+    return p.N == V5_BN && v6_plan(p, &pl) && pl.bn == V5_BN && !pl.up;
 }
 
 int gemm_launch(const GemmParams& pin, hipStream_t stream) {
@@ -2399,36 +2438,56 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
 
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     // ---- v6 (halo-tile 3x3 convolution on the v5 skeleton): stride-1 convs whose tiles are whole image rows and fill the chip
-    int sk6 = 0, bn6 = 0;
-    if (v6_plan(p, &sk6, &bn6)) {
-        const long long t6 = (long long)(p.M / V5_BM) * (p.N / bn6);
+    V6Plan pl;
+    if (v6_plan(p, &pl)) {
+        const int sk6 = pl.sk, bn6 = pl.bn, wc = pl.wc;
+        const long long t6 = (long long)(p.M / pl.bm) * (p.N / bn6);
         p.splitk = sk6;
         p.pad = 1;
         p.n_valid = p.N;
         dim3 grid((unsigned)(t6 * sk6), 1, 1);
+        const bool wide = p.Wo > 128;
         if (p.gn_scale != nullptr) {
-            if (p.gn_shift == nullptr || bn6 != V5_BN) return LD_ERR_ARG;
-            t_last_kernel = p.Wo == 16 ? "conv6_kernel<W16,halo+groupnorm>" : p.Wo == 32 ? "conv6_kernel<W32,halo+groupnorm>"
-                          : p.Wo == 64 ? "conv6_kernel<W64,halo+groupnorm>" : "conv6_kernel<W128,halo+groupnorm>";
-            switch (p.Wo) {
+            if (p.gn_shift == nullptr || bn6 != V5_BN || pl.up) return LD_ERR_ARG;
+            t_last_kernel = wc == 16 ? "conv6_kernel<W16,halo+groupnorm>" : wc == 32 ? "conv6_kernel<W32,halo+groupnorm>"
+                          : wc == 64 ? "conv6_kernel<W64,halo+groupnorm>" : "conv6_kernel<W128,halo+groupnorm>";
+            switch (wc) {
                 case 16: hipLaunchKernelGGL((conv6_kernel<16, true>), grid, dim3(512), 0, stream, p); break;
                 case 32: hipLaunchKernelGGL((conv6_kernel<32, true>), grid, dim3(512), 0, stream, p); break;
                 case 64: hipLaunchKernelGGL((conv6_kernel<64, true>), grid, dim3(512), 0, stream, p); break;
                 default: hipLaunchKernelGGL((conv6_kernel<128, true>), grid, dim3(512), 0, stream, p); break;
             }
+        } else if (bn6 == 128) {
+            t_last_kernel = "conv6_kernel<W128,halo,128x512>";
+            hipLaunchKernelGGL((conv6_kernel<128, false, 128, 512>), grid, dim3(512), 0, stream, p);
         } else if (bn6 == 256) {
-            t_last_kernel = p.Wo == 64 ? "conv6_kernel<W64,halo,256>" : "conv6_kernel<W128,halo,256>";
-            if (p.Wo == 64) hipLaunchKernelGGL((conv6_kernel<64, false, 256>), grid, dim3(512), 0, stream, p);
-            else hipLaunchKernelGGL((conv6_kernel<128, false, 256>), grid, dim3(512), 0, stream, p);
+            if (pl.up) {
+                t_last_kernel = wc == 64 ? "conv6_kernel<W64,halo,256,up>" : "conv6_kernel<W128,halo,256,up>";
+                if (wc == 64) hipLaunchKernelGGL((conv6_kernel<64, false, 256, V5_BM, true>), grid, dim3(512), 0, stream, p);
+                else hipLaunchKernelGGL((conv6_kernel<128, false, 256, V5_BM, true>), grid, dim3(512), 0, stream, p);
+            } else {
+                t_last_kernel = wc == 64 ? "conv6_kernel<W64,halo,256>" : "conv6_kernel<W128,halo,256>";
+                if (wc == 64) hipLaunchKernelGGL((conv6_kernel<64, false, 256>), grid, dim3(512), 0, stream, p);
+                else hipLaunchKernelGGL((conv6_kernel<128, false, 256>), grid, dim3(512), 0, stream, p);
+            }
+        } else if (pl.up) {
+            t_last_kernel = wc == 16 ? "conv6_kernel<W16,halo,up>" : wc == 32 ? "conv6_kernel<W32,halo,up>" : wc == 64 ? "conv6_kernel<W64,halo,up>" : "conv6_kernel<W128,halo,up>";
+            switch (wc) {
+                case 16: hipLaunchKernelGGL((conv6_kernel<16, false, V5_BN, V5_BM, true>), grid, dim3(512), 0, stream, p); break;
+                case 32: hipLaunchKernelGGL((conv6_kernel<32, false, V5_BN, V5_BM, true>), grid, dim3(512), 0, stream, p); break;
+                case 64: hipLaunchKernelGGL((conv6_kernel<64, false, V5_BN, V5_BM, true>), grid, dim3(512), 0, stream, p); break;
+                default: hipLaunchKernelGGL((conv6_kernel<128, false, V5_BN, V5_BM, true>), grid, dim3(512), 0, stream, p); break;
+            }
         } else {
-            t_last_kernel = p.Wo == 16 ? "conv6_kernel<W16,halo>" : p.Wo == 32 ? "conv6_kernel<W32,halo>" : p.Wo == 64 ? "conv6_kernel<W64,halo>" : "conv6_kernel<W128,halo>";
-            switch (p.Wo) {
+            t_last_kernel = wc == 16 ? "conv6_kernel<W16,halo>" : wc == 32 ? "conv6_kernel<W32,halo>" : wc == 64 ? "conv6_kernel<W64,halo>" : "conv6_kernel<W128,halo>";
+            switch (wc) {
                 case 16: hipLaunchKernelGGL((conv6_kernel<16, false>), grid, dim3(512), 0, stream, p); break;
                 case 32: hipLaunchKernelGGL((conv6_kernel<32, false>), grid, dim3(512), 0, stream, p); break;
                 case 64: hipLaunchKernelGGL((conv6_kernel<64, false>), grid, dim3(512), 0, stream, p); break;
                 default: hipLaunchKernelGGL((conv6_kernel<128, false>), grid, dim3(512), 0, stream, p); break;
             }
         }
+        (void)wide;
         if (sk6 > 1) launch_splitk_reduce(p, 160, stream);
         return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
     }
