@@ -79,3 +79,5 @@ int gemm_launch(const GemmParams& p, hipStream_t stream);
 // true when gemm_launch would run this convolution on the halo-tile kernel, i.e. when it can take gn_scale / gn_shift
 // (fill every other field first; gemm_launch rejects gn_scale on any other path)
 bool gemm_conv_fuses_groupnorm(const GemmParams& p);
+// does gemm_launch run this convolution on the halo-tile kernel?  (callers that need a property of it: the VAE's MFMA output conv)
+bool gemm_conv_takes_halo_tile(const GemmParams& p);

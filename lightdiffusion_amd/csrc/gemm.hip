@@ -1222,7 +1222,8 @@ __device__ __forceinline__ void v6_finish(const GemmParams& p, f32x4 (&acc)[TM][
                 else if (p.act == 3) t = quick_gelu_f(t);
                 v[j] = t + r[j];
             }
-            if ((TOT % 64 == 0 || q0 < TOT) && m_base + row < p.M) st16(p.C + (long long)(m_base + row) * p.ldc + n_w + cc * 8, pack8(v));
+            if ((TOT % 64 == 0 || q0 < TOT) && m_base + row < p.M && n_w + cc * 8 < p.n_valid)
+                st16(p.C + (long long)(m_base + row) * p.ldc + n_w + cc * 8, pack8(v));
         }
     };
     half_t* Cs1 = Cs0 + 16 * LD;
@@ -1484,7 +1485,7 @@ template <int W, bool GN, int BN = V5_BN, int BM = V5_BM, bool UP = false>
                                             // registers); BN: tile width 320 (the UNet's N = 320 k), 256 (the VAE's N = 256 / 512) or 128 (its N = 128)
 __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     constexpr int TM = BM / 64, TN = BN / 32;
-    static_assert(BN == 320 || BN == 256 || BN == 160 || BN == 128, "tile width");
+    static_assert(BN == 320 || BN == 256 || BN == 160 || BN == 128 || BN == 32, "tile width");
     static_assert(BM == 256 || (BM == 512 && W == 128), "tile height: 256 pixels, or four rows of a 128-pixel band");
     static_assert(!GN || BN == V5_BN, "the fused GroupNorm only pays where the output is one 320-column tile wide");
     static_assert(!(GN && UP), "no caller");
@@ -2303,7 +2304,9 @@ extern "C" void ld_debug_gemm_v5_dbg(int bits) { g_v5_dbg = bits; }   // 1: no D
 
 // the split-K second pass of a launch: the plain reduce, or the one that also emits GroupNorm partials (GemmParams::gn_part)
 static void launch_splitk_reduce(const GemmParams& p, int bn, hipStream_t stream) {
-    const bool gn = p.gn_part != nullptr && p.act != 2 && p.batch == 1 && p.gn_P > 0 && p.gn_HW > 0 && p.M % p.gn_HW == 0 && p.N % 32 == 0 && p.N <= 8192 &&
+    // (N >= 256: below that gn_stats_kernel uses fewer, wider channel slabs — norm.hip gn_slabs — and this kernel's four-slab order would
+    // no longer reproduce its partials bit for bit)
+    const bool gn = p.gn_part != nullptr && p.act != 2 && p.batch == 1 && p.gn_P > 0 && p.gn_HW > 0 && p.M % p.gn_HW == 0 && p.N % 32 == 0 && p.N <= 8192 && p.N >= 256 &&
                     p.ldc == p.N && (p.N / 4) % 8 == 0 && p.N / 32 <= 256;
     if (gn) {
         hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3(p.gn_P, p.M / p.gn_HW, 4), dim3(256), 0, stream, p);
@@ -2372,6 +2375,11 @@ static bool v6_plan(const GemmParams& p, V6Plan* out) {
     ) {
         bn = 128;
         bm = 512;
+    } else if (p.N == 32 && wc == 128 && p.gn_scale == nullptr && !up) {
+        // a <= 8-channel output convolution (the VAE's conv_out, weights zero-padded to 32 rows by the caller, n_valid = 8): 8 MFMAs per
+        // wave and phase — the step's fixed cost dominates, but the halo tile is read once instead of nine times per pixel
+        bn = 32;
+        bm = 512;
     } else {
         return false;
     }
@@ -2395,6 +2403,12 @@ static bool v6_plan(const GemmParams& p, V6Plan* out) {
     out->wc = wc;
     out->up = up;
     return t6 * sk6 >= 192;
+}
+
+bool gemm_conv_takes_halo_tile(const GemmParams& pin) {
+    GemmParams p = pin;
+    V6Plan pl;
+    return v6_plan(p, &pl);
 }
 
 bool gemm_conv_fuses_groupnorm(const GemmParams& p) {
@@ -2444,7 +2458,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         const long long t6 = (long long)(p.M / pl.bm) * (p.N / bn6);
         p.splitk = sk6;
         p.pad = 1;
-        p.n_valid = p.N;
+        if (bn6 != 32) p.n_valid = p.N;                              // (the 32-column tile stores only the caller's n_valid columns)
         dim3 grid((unsigned)(t6 * sk6), 1, 1);
         const bool wide = p.Wo > 128;
         if (p.gn_scale != nullptr) {
@@ -2460,6 +2474,9 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         } else if (bn6 == 128) {
             t_last_kernel = "conv6_kernel<W128,halo,128x512>";
             hipLaunchKernelGGL((conv6_kernel<128, false, 128, 512>), grid, dim3(512), 0, stream, p);
+        } else if (bn6 == 32) {
+            t_last_kernel = "conv6_kernel<W128,halo,32x512>";
+            hipLaunchKernelGGL((conv6_kernel<128, false, 32, 512>), grid, dim3(512), 0, stream, p);
         } else if (bn6 == 256) {
             if (pl.up) {
                 t_last_kernel = wc == 64 ? "conv6_kernel<W64,halo,256,up>" : "conv6_kernel<W128,halo,256,up>";

@@ -74,6 +74,10 @@ struct SmallConvOutArgs {       // 3x3 pad-1 conv to <= 4 output channels from a
 };
 int small_conv_out_launch(const SmallConvOutArgs& a, hipStream_t stream);
 
+// VAE output tail behind the MFMA output convolution: t8 [npix][8] fp16 (first `cout` columns valid) -> out [npix][cout] fp32 =
+// clamp((v + 1) / 2, 0, 1)  (VAE.process_output, LD.py:6296-6298)
+int vae_out_finish_launch(const half_t* t8, float* out, long long npix, int cout, hipStream_t stream);
+
 int small_pointwise_launch(const half_t* x, const half_t* w, const half_t* b, float* out, int N, int HW, int C, hipStream_t stream);
 
 // timestep lookup + sinusoidal embedding: sigma[N] -> t = argmin |log sigma - log_sigmas| -> [N][dim] fp16 (cos | sin)

@@ -191,6 +191,14 @@ __global__ void small_pointwise_kernel(const half_t* x, const half_t* w, const h
     }
 }
 
+__global__ void vae_out_finish_kernel(const half_t* __restrict__ t8, float* __restrict__ out, long long npix, int cout) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < npix; q += (long long)gridDim.x * blockDim.x) {
+        float v[8];
+        unpack8(ld16(t8 + q * 8), v);
+        for (int o = 0; o < cout; ++o) out[q * cout + o] = fminf(fmaxf((v[o] + 1.0f) * 0.5f, 0.0f), 1.0f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ timestep embedding
 // ModelSamplingDiscrete.timestep (LD.py:1336-1339) + timestep_embedding (LD.py:803-812).  One block per sample.
 __global__ __launch_bounds__(256) void timestep_embed_kernel(const float* sigma, const float* log_sigmas, int n_sig, int dim,
@@ -332,6 +340,12 @@ int small_conv_out_launch(const SmallConvOutArgs& a, hipStream_t stream) {
     if (nch <= 3) hipLaunchKernelGGL((small_conv_out_kernel<3, 4>), grid, block, 0, stream, a);
     else if (nch <= 6) hipLaunchKernelGGL((small_conv_out_kernel<6, 2>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((small_conv_out_kernel<9, 1>), grid, block, 0, stream, a);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int vae_out_finish_launch(const half_t* t8, float* out, long long npix, int cout, hipStream_t stream) {
+    if (t8 == nullptr || out == nullptr || cout < 1 || cout > 8) return LD_ERR_ARG;
+    hipLaunchKernelGGL(vae_out_finish_kernel, dim3(grid_for(npix, 256)), dim3(256), 0, stream, t8, out, npix, cout);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
 

@@ -10,12 +10,16 @@
 namespace {
 
 constexpr int GN_THREADS = 256;
-constexpr int GN_SLABS = 4;       // channel slabs of 8 groups each: grid.z
+// channel slabs (grid.z) of 32 / slabs groups each: 4 from C = 256 on (a block's pixel row segment is then >= 128 bytes); fewer for
+// narrow tensors so that a segment stays a whole 128-byte line — with four 64-byte slabs the VAE's C = 128 GroupNorms ran at 3.1 TB/s
+// against 5.3 TB/s for C = 256 / 512 (profiles/r03a_vae512_launches.txt).  The UNet's tensors (C >= 320) keep 4: summation order unchanged.
+__host__ __device__ inline int gn_slabs(int C) { return C >= 256 ? 4 : C >= 128 ? 2 : 1; }
 
 struct GnArgs {
     const half_t* x1;
     const half_t* x2;
     int C1, C2, HW, P, ppb;   // P pixel-chunks per image, ppb pixels per chunk
+    int slabs;                // gn_slabs(C1 + C2)
     float* partial;           // [N][P][32][2]
     const half_t* gamma;
     const half_t* beta;
@@ -35,7 +39,8 @@ __device__ __forceinline__ const half_t* gn_src(const GnArgs& a, int n, int pix,
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
     __shared__ float csum[2048], csq[2048];   // [rows_par][slab channels], rows_par * CS <= 256 * 8
     const int C = a.C1 + a.C2, cpg = C / 32;
-    const int CS = C / GN_SLABS, CHS = CS >> 3;                 // slab channels / chunks
+    const int CS = C / a.slabs, CHS = CS >> 3;                  // slab channels / chunks
+    const int gps = 32 / a.slabs, lpg = GN_THREADS / gps;       // groups per slab, lanes per group in the final reduction (32 / 16 / 8)
     const int n = blockIdx.y, pc = blockIdx.x, slab = blockIdx.z, tid = threadIdx.x;
     const int rows_par = GN_THREADS / CHS;
     const int cc = tid % CHS, prow = tid / CHS;
@@ -82,21 +87,20 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
     }
     __syncthreads();
     {
-        const int g = tid >> 5, sub = tid & 31;                  // 8 groups x 32 lanes
+        const int g = tid / lpg, sub = tid - g * lpg;            // gps groups x lpg lanes (4 slabs: 8 x 32)
         const int cnt = rows_par * cpg;
         float s = 0.f, ss = 0.f;
-        for (int i = sub; i < cnt; i += 32) {
+        for (int i = sub; i < cnt; i += lpg) {
             const int pr = i / cpg, c = g * cpg + (i - pr * cpg);
             s += csum[pr * CS + c];
             ss += csq[pr * CS + c];
         }
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
+        for (int o = 1; o < lpg; o <<= 1) {
             s += __shfl_xor(s, o, 64);
             ss += __shfl_xor(ss, o, 64);
         }
         if (sub == 0) {
-            float* o = a.partial + (((long long)n * a.P + pc) * 32 + slab * 8 + g) * 2;
+            float* o = a.partial + (((long long)n * a.P + pc) * 32 + slab * gps + g) * 2;
             o[0] = s;
             o[1] = ss;
         }
@@ -104,20 +108,20 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GnArgs a) {
 }
 
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
-    __shared__ float mean[8], rstd[8];
+    __shared__ float mean[32], rstd[32];
     const int C = a.C1 + a.C2, cpg = C / 32;
-    const int CS = C / GN_SLABS, CHS = CS >> 3;
+    const int CS = C / a.slabs, CHS = CS >> 3;
+    const int gps = 32 / a.slabs, lpg = GN_THREADS / gps;
     const int n = blockIdx.y, pc = blockIdx.x, slab = blockIdx.z, tid = threadIdx.x;
-    {   // finish the statistics of this slab's 8 groups: 32 lanes per group sweep the P partial slabs in a fixed order
-        const int g = tid >> 5, sub = tid & 31;
+    {   // finish the statistics of this slab's groups: lpg lanes per group sweep the P partial slabs in a fixed order
+        const int g = tid / lpg, sub = tid - g * lpg;
         float s = 0.f, ss = 0.f;
-        const float* pp = a.partial + ((long long)n * a.P * 32 + slab * 8 + g) * 2;
-        for (int i = sub; i < a.P; i += 32) {
+        const float* pp = a.partial + ((long long)n * a.P * 32 + slab * gps + g) * 2;
+        for (int i = sub; i < a.P; i += lpg) {
             s += pp[(long long)i * 64];
             ss += pp[(long long)i * 64 + 1];
         }
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
+        for (int o = 1; o < lpg; o <<= 1) {
             s += __shfl_xor(s, o, 64);
             ss += __shfl_xor(ss, o, 64);
         }
@@ -173,19 +177,19 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
 // convolution, gemm.h gn_scale / gn_shift): same reduction order and the same  sc = rstd * gamma,  sh = beta - mean * sc  as
 // gn_apply_kernel, so the fused path reproduces the two-pass one bit for bit.  One block per (image, slab of 8 groups).
 __global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(const GnArgs a, float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ float mean[8], rstd[8];
-    const int C = a.C1 + a.C2, cpg = C / 32, CS = C / GN_SLABS;
+    __shared__ float mean[32], rstd[32];
+    const int C = a.C1 + a.C2, cpg = C / 32, CS = C / a.slabs;
+    const int gps = 32 / a.slabs, lpg = GN_THREADS / gps;
     const int n = blockIdx.x, slab = blockIdx.y, tid = threadIdx.x;
     {
-        const int g = tid >> 5, sub = tid & 31;
+        const int g = tid / lpg, sub = tid - g * lpg;
         float s = 0.f, ss = 0.f;
-        const float* pp = a.partial + ((long long)n * a.P * 32 + slab * 8 + g) * 2;
-        for (int i = sub; i < a.P; i += 32) {
+        const float* pp = a.partial + ((long long)n * a.P * 32 + slab * gps + g) * 2;
+        for (int i = sub; i < a.P; i += lpg) {
             s += pp[(long long)i * 64];
             ss += pp[(long long)i * 64 + 1];
         }
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) {
+        for (int o = 1; o < lpg; o <<= 1) {
             s += __shfl_xor(s, o, 64);
             ss += __shfl_xor(ss, o, 64);
         }
@@ -309,7 +313,8 @@ int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_i
     a.P = gn_num_chunks(n_img, HW);
     a.ppb = (HW + a.P - 1) / a.P;
     a.partial = partial; a.gamma = gamma; a.beta = beta; a.y = y; a.eps = eps; a.silu = silu;
-    dim3 grid(a.P, n_img, GN_SLABS);
+    a.slabs = gn_slabs(C);
+    dim3 grid(a.P, n_img, a.slabs);
     if (!stats_ready) hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, stream, a);   // (ready: the producer's split-K reduce wrote `partial`, gemm.h gn_part)
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), 0, stream, a);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
@@ -325,8 +330,9 @@ int groupnorm_scale_shift_launch(const half_t* x1, int C1, const half_t* x2, int
     a.P = gn_num_chunks(n_img, HW);
     a.ppb = (HW + a.P - 1) / a.P;
     a.partial = partial; a.gamma = gamma; a.beta = beta; a.y = nullptr; a.eps = eps; a.silu = 0;
-    if (!stats_ready) hipLaunchKernelGGL(gn_stats_kernel, dim3(a.P, n_img, GN_SLABS), dim3(GN_THREADS), 0, stream, a);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img, GN_SLABS), dim3(GN_THREADS), 0, stream, a, scale, shift);
+    a.slabs = gn_slabs(C);
+    if (!stats_ready) hipLaunchKernelGGL(gn_stats_kernel, dim3(a.P, n_img, a.slabs), dim3(GN_THREADS), 0, stream, a);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_img, a.slabs), dim3(GN_THREADS), 0, stream, a, scale, shift);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
 

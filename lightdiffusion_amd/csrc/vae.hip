@@ -45,6 +45,7 @@ struct ld_vae {
     double last_flops = 0.0;
     Timing timing;
     bool want_timing = false;
+    half_t* co_pad = nullptr;             // conv_out weights zero-padded to 32 output rows + 32 biases (MFMA output conv)
 };
 
 namespace {
@@ -319,14 +320,45 @@ int run_decode(ld_vae* v, bool dry, const float* z, float* out, int b, int h, in
     {
         half_t* g = ar.halfs((size_t)b * H * W * C);
         ex.groupnorm(f, C, nullptr, 0, b, H * W, v->pt.ptr(v->no_g), v->pt.ptr(v->no_b), 1e-6f, 1, g);
-        SmallConvOutArgs a;
-        a.x = g; a.w = v->pt.ptr(v->co_w); a.b = v->pt.ptr(v->co_b);
-        a.N = b; a.H = H; a.W = W; a.Cin = C; a.Cout = c.out_ch; a.mode = 1; a.out = out;
-        ex.launches += 1;
-        ex.flops += 2.0 * b * H * W * C * 9.0 * c.out_ch;
-        ex.t_begin(KC_MISC, 2.0 * b * H * W * C * 9.0 * c.out_ch, 1, "conv_out", (long long)b * H * W, c.out_ch, 9 * C, 1);
-        if (!dry) ex.note(small_conv_out_launch(a, stream));
-        ex.t_end("small_conv_out_kernel");
+        // conv_out (C -> 3): on the halo-tile MFMA kernel when the image is cut into its 4-row x 128-pixel tiles (weights zero-padded to
+        // 32 rows, 8 stored columns, then one elementwise pass for clamp((v + 1) / 2) -> fp32 NHWC): 1427 -> ~200 us at 512x512 x 8;
+        // other sizes keep the vector-ALU kernel
+        GemmParams q;
+        q.conv = 1; q.ksize = 3; q.pad = -1; q.stride = 1;
+        q.A = g; q.C1 = C;
+        q.Hs = H; q.Ws = W; q.Hv = H; q.Wv = W; q.Ho = H; q.Wo = W;
+        q.W = v->co_pad; q.ldw = 9 * C;
+        q.M = b * H * W; q.N = 32; q.n_valid = 8; q.K = 9 * C;
+        q.bias_n = v->co_pad != nullptr ? v->co_pad + (size_t)32 * 9 * C : nullptr;
+        q.partial = ex.splitk_ws; q.partial_bytes = ex.splitk_bytes;
+        if (v->co_pad != nullptr && c.out_ch <= 8 && gemm_conv_takes_halo_tile(q)) {
+            half_t* t8 = ar.halfs((size_t)b * H * W * 8);
+            q.C = t8; q.ldc = 8;
+            if (!dry) {   // the three real rows of the weight matrix and the biases into the padded copies (stream-ordered, 7 KB)
+                const size_t wb = (size_t)c.out_ch * 9 * C * sizeof(half_t);
+                if (hipMemcpyAsync(v->co_pad, v->pt.ptr(v->co_w), wb, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+                    hipMemcpyAsync(v->co_pad + (size_t)32 * 9 * C, v->pt.ptr(v->co_b), c.out_ch * sizeof(half_t), hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                    ex.note(LD_ERR_HIP);
+            }
+            const double fl = 2.0 * b * H * W * C * 9.0 * c.out_ch;
+            ex.launches += 2;
+            ex.flops += fl;
+            ex.t_begin(KC_CONV3, fl, 1, "conv_out", (long long)b * H * W, c.out_ch, 9 * C, 1);
+            if (!dry && ex.status == LD_OK) ex.note(gemm_launch(q, stream));
+            ex.t_end(gemm_last_kernel_name());
+            ex.t_begin(KC_MISC, 0.0, 1, "out_finish", (long long)b * H * W, c.out_ch, 0, 1);
+            if (!dry && ex.status == LD_OK) ex.note(vae_out_finish_launch(t8, out, (long long)b * H * W, c.out_ch, stream));
+            ex.t_end("vae_out_finish_kernel");
+        } else {
+            SmallConvOutArgs a;
+            a.x = g; a.w = v->pt.ptr(v->co_w); a.b = v->pt.ptr(v->co_b);
+            a.N = b; a.H = H; a.W = W; a.Cin = C; a.Cout = c.out_ch; a.mode = 1; a.out = out;
+            ex.launches += 1;
+            ex.flops += 2.0 * b * H * W * C * 9.0 * c.out_ch;
+            ex.t_begin(KC_MISC, 2.0 * b * H * W * C * 9.0 * c.out_ch, 1, "conv_out", (long long)b * H * W, c.out_ch, 9 * C, 1);
+            if (!dry) ex.note(small_conv_out_launch(a, stream));
+            ex.t_end("small_conv_out_kernel");
+        }
     }
     v->last_launches = ex.launches;
     v->last_flops = ex.flops;
@@ -408,9 +440,15 @@ int ld_vae_create(const ld_vae_config* cfg, ld_vae** out) {
     if (cfg == nullptr || out == nullptr) return LD_ERR_ARG;
     ld_vae* v = new ld_vae();
     v->cfg = *cfg;
-    const int st = build(v);
+    int st = build(v);
+    if (st == LD_OK) {   // zero-padded [32][9 C] conv_out weights + 32 biases for the MFMA output convolution (rows >= out_ch stay zero)
+        const int C0 = v->cfg.ch * v->cfg.ch_mult[0];
+        const size_t bytes = ((size_t)32 * 9 * C0 + 32) * sizeof(half_t);
+        if (hipMalloc((void**)&v->co_pad, bytes) != hipSuccess || hipMemset(v->co_pad, 0, bytes) != hipSuccess) st = LD_ERR_HIP;
+    }
     if (st != LD_OK) {
         v->pt.destroy();
+        if (v->co_pad) (void)hipFree(v->co_pad);
         delete v;
         return st;
     }
@@ -422,6 +460,7 @@ void ld_vae_destroy(ld_vae* v) {
     if (v == nullptr) return;
     v->pt.destroy();
     v->timing.destroy();
+    if (v->co_pad) (void)hipFree(v->co_pad);
     if (v->ws_base) (void)hipFree(v->ws_base);
     delete v;
 }
