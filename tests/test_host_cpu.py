@@ -389,3 +389,26 @@ def test_lora_alias_patches_a_weight_once():
     winner = [n for n in km if km[n] == key and n in (ldm, dif)][-1]            # last alias in key-map order wins
     u, dn = (up, down) if winner == ldm else (up2, down2)
     assert torch.allclose(sd[key], before + u @ dn, atol=1e-5)
+
+
+def test_bench_roofline_pricing():
+    """bench.py prices a kernel against the roof its arithmetic intensity puts it under (ridge = 2.5 PFLOP/s / 8 TB/s), from the per-launch
+    table of `ld_unet_profile_launches`, and reports PMC traffic only when the pass was taken with the library that is loaded."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ld_bench_roofs", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.launch_min_bytes("gemm", (128, 1280, 1280, 1)) == 2.0 * (128 * 1280 + 1280 * 1280 + 128 * 1280)
+    assert bench.launch_min_bytes("conv3", (65536, 320, 2880, 1)) == 2.0 * (65536 * 320 + 320 * 2880 + 65536 * 320)     # raw pixels x Cin, not the im2col
+    assert bench.launch_min_bytes("geglu", (4096, 10240, 1280, 1)) == 2.0 * (4096 * 1280 + 10240 * 1280 + 4096 * 5120)
+    assert bench.launch_min_bytes("attention", (128, 4096, 4096, 40)) == 2.0 * 128 * (2 * 4096 * 40 + 2 * 4096 * 40)
+    rows = [("conv3", (65536, 320, 2880, 1), 2.0 * 65536 * 320 * 2880, 130.0, "big_conv"),
+            ("gemm", (128, 1280, 1280, 1), 2.0 * 128 * 1280 * 1280, 8.0, "skinny"), ("gemm", (128, 1280, 1280, 1), 2.0 * 128 * 1280 * 1280, 8.0, "skinny")]
+    stale = lambda kern: (None, None, "profiles/pmc_traffic.json[x] lib abc (stale: loaded library is def)")
+    dom, hbm = bench.rooflines(rows, {"big_conv": 0.130, "skinny": 0.016}, stale)
+    assert dom["kernel"] == "big_conv" and dom["bound"] == "mfma" and dom["unit"] == "TFLOP/s"
+    assert abs(dom["achieved"] - rows[0][2] / 130e-6 / 1e12) < 1e-6 and abs(dom["frac"] - dom["achieved"] / 2500.0) < 1e-9
+    assert dom["traffic"] is None and "stale" in dom["traffic_from"]
+    assert hbm["kernel"] == "skinny" and hbm["bound"] == "hbm" and hbm["unit"] == "GB/s" and hbm["launches"] == 2
+    b = bench.launch_min_bytes("gemm", (128, 1280, 1280, 1))
+    assert abs(hbm["achieved"] - 2 * b / 16e-6 / 1e9) < 1e-6 and hbm["intensity_flop_per_byte"] < bench.RIDGE

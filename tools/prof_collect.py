@@ -20,10 +20,15 @@ def short_name(k):
     m = re.match(r"gemm5_kernel<(true|false)(?:, \d+)?>", k)
     if m:
         return f"gemm5_kernel<256,320,{'conv' if m.group(1) == 'true' else 'plain'}>"
-    m = re.match(r"conv6_kernel<(\d+), (true|false)(?:, (\d+))?(?:, (true|false))?>", k)
-    if m:
-        return f"conv6_kernel<W{m.group(1)},{'halo+groupnorm' if m.group(2) == 'true' else 'halo'}" + (f",{m.group(3)}" if m.group(3) and m.group(3) != "320" else "") + \
-               (",up" if m.group(4) == "true" else "") + ">"
+    m = re.match(r"conv6_kernel<(\d+), (true|false)(?:, (\d+))?(?:, (\d+))?(?:, (true|false))?>", k)
+    if m:   # the names gemm_launch gives its instantiations (bench.py prints those)
+        w, gn, bn, bm, up = m.group(1), m.group(2) == "true", m.group(3) or "320", m.group(4) or "256", m.group(5) == "true"
+        tail = ""
+        if bm != "256":
+            tail = f",{bn}x{bm}"
+        elif bn != "320":
+            tail = f",{bn}"
+        return f"conv6_kernel<W{w},{'halo+groupnorm' if gn else 'halo'}{tail}{',up' if up else ''}>"
     m = re.match(r"gemm7_kernel<(true|false)(?:, (?:true|false))?>", k)
     if m:
         return f"gemm7_kernel<256,K320,{'geglu' if m.group(1) == 'true' else 'plain'}>"
