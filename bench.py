@@ -400,7 +400,7 @@ def main():
         "launches_per_forward": head["launches_per_forward"],
         "cond_broadcast_ms": 1e3 * t_bcast, "weights_load_s": t_load,
         "kernel_class_ms_per_forward": head["kernel_class_ms_per_forward"], "kernels_ms_per_forward": head["kernels_ms_per_forward"],
-        "roofline": head["roofline"],
+        "roofline": head["roofline"], "roofline_hbm": head.get("roofline_hbm"),
     }
     out.update(out_extra)
 
