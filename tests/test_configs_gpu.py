@@ -91,6 +91,27 @@ def test_vae_decode_512_and_1024(hw, sub):
     torch.cuda.empty_cache()
 
 
+def test_vae_decode_non_square_bands_against_oracle():
+    """SD1.5 VAE decoder on a NON-square latent (48 x 32 -> 384 x 256 pixels), batch 2: rows of 32 / 64 pixels (too few halo tiles at this size: implicit-GEMM kernel + split-K), 128 pixels
+    (halo tiles of whole rows), 256 pixels (two 128-pixel column bands per row, 4-row x 128-column tiles for N = 128, the upsampling loader
+    into a banded image) and the MFMA output convolution with exactly 192 tiles per image pair — against the oracle on the host."""
+    from lightdiffusion_amd.unet import synthetic_vae
+    from oracle import sd15_ref as O
+    cfg = W.sd15_vae_config()
+    v = synthetic_vae(cfg, max_batch=2, max_hw=(48, 32))
+    z = torch.randn(2, 4, 48, 32, generator=torch.Generator().manual_seed(23)) * (0.2 / 0.18215)
+    img = v.decode(z)
+    assert img.shape == (2, 384, 256, 3)
+    kinds = {r[4] for r in v.profile_decode(z)}
+    assert {"conv6_kernel<W128,halo,128x512>", "conv6_kernel<W128,halo,256,up>", "conv6_kernel<W128,halo,256>", "conv6_kernel<W128,halo,32x512>"} <= kinds, kinds
+    ref = O.vae_decode(W.synth_state_dict(W.vae_decoder_param_shapes(cfg)), cfg, z[:1])
+    assert float((img[:1] - ref).abs().max()) < 2.0 / 255.0
+    img1 = v.decode(z[1:])                                     # batch 1: other tile counts (the output conv falls back below 192 tiles)
+    assert float((img1 - img[1:]).abs().max()) < 1.0 / 255.0
+    del v
+    torch.cuda.empty_cache()
+
+
 def test_vae_latents_not_multiple_of_8():
     """5x7 and 3x3 latents: the mid-block attention's key axis (h*w = 35 / 9) is not a multiple of 8 (padded, masked softmax)."""
     from lightdiffusion_amd.unet import synthetic_vae
