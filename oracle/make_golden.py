@@ -289,6 +289,25 @@ def g_tokens():
     print("wrote token_chunks.json", {k[:20]: len(v) for k, v in out.items()})
 
 
+# ------------------------------------------------------------------ 6c. the same with the REAL CLIP tokenizer (vocabulary files of the reference checkout)
+REAL_PROMPTS = ["a photo of a cat", "masterpiece, (best quality:1.2), 1girl, ((detailed eyes)), [blurry]", "",
+                "a \\(literal\\) paren and (nested (deep:1.5) words:0.8)",
+                " ".join(["extraordinarily"] * 45) + " long prompt that spills into a second chunk of seventy seven tokens, (weighted tail:1.3)"]
+
+
+def g_tokens_real():
+    """SDTokenizer (LD.py:4936-5031) over HuggingFace's CLIPTokenizer with the vocabulary of `_internal/sd1_tokenizer/` (which stays in the
+    reference checkout: the fixture holds prompts and token ids only).  tests/test_host_cpu.py compares PromptTokenizer.from_pretrained on the
+    same directory when it is present."""
+    os.environ.setdefault("HF_HUB_OFFLINE", "1")
+    from transformers import CLIPTokenizer
+    tok = ref.SDTokenizer(tokenizer_path=os.path.join(os.path.dirname(REF_PATH), "_internal", "sd1_tokenizer"), tokenizer_class=CLIPTokenizer)
+    out = {p: tok.tokenize_with_weights(p) for p in REAL_PROMPTS}
+    with open(os.path.join(OUT, "token_chunks_real.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote token_chunks_real.json", {k[:20]: len(v) for k, v in out.items()})
+
+
 # ------------------------------------------------------------------ 7. bislerp
 def g_bislerp():
     x = rnd((2, 4, 8, 6), 71)
@@ -569,6 +588,7 @@ def g_multicond():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "blocks", "unets", "samplers", "vae", "vae_enc", "clip", "tokens", "bislerp", "configs", "lora"]
+    # (`e2e` takes ~8 min, `tokens_real` needs the reference checkout's tokenizer files and transformers: both on request)
+    which = sys.argv[1:] or ["schedules", "blocks", "unets", "samplers", "vae", "vae_enc", "clip", "tokens", "bislerp", "configs", "lora", "multicond"]
     for n in which:
         globals()["g_" + n]()

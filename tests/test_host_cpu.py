@@ -412,3 +412,21 @@ def test_bench_roofline_pricing():
     assert hbm["kernel"] == "skinny" and hbm["bound"] == "hbm" and hbm["unit"] == "GB/s" and hbm["launches"] == 2
     b = bench.launch_min_bytes("gemm", (128, 1280, 1280, 1))
     assert abs(hbm["achieved"] - 2 * b / 16e-6 / 1e9) < 1e-6 and hbm["intensity_flop_per_byte"] < bench.RIDGE
+
+
+def test_real_clip_tokenizer_matches_reference():
+    """PromptTokenizer.from_pretrained on the reference checkout's CLIP vocabulary (HuggingFace CLIPTokenizer underneath, as the reference uses)
+    against SDTokenizer.tokenize_with_weights on the same files: BOS / EOS ids read from the tokenizer, emphasis weights, escapes, a prompt that
+    spills into a second 77-token chunk.  The vocabulary does not travel with this repository: skipped where the checkout is absent."""
+    tdir = os.path.join(os.path.dirname(os.environ.get("LD_REFERENCE", "/root/reference/LightDiffusion.py")), "_internal", "sd1_tokenizer")
+    if not os.path.exists(os.path.join(tdir, "vocab.json")):
+        pytest.skip("reference tokenizer files not present")
+    pytest.importorskip("transformers")
+    os.environ.setdefault("HF_HUB_OFFLINE", "1")
+    from lightdiffusion_amd.clip import PromptTokenizer
+    tok = PromptTokenizer.from_pretrained(tdir)
+    want = json.load(open(os.path.join(GOLDEN, "token_chunks_real.json")))
+    assert any(len(v) > 1 for v in want.values())
+    for text, chunks in want.items():
+        got = tok.tokenize_with_weights(text)
+        assert [[list(p) for p in c] for c in got] == chunks, text
