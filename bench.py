@@ -290,7 +290,7 @@ def main():
         agg = {}
         cls = None
         for _ in range(3):
-            c = unet.profile(den.x2, den.sigma2)
+            c = unet.profile_pair(den.x1, den.sigma1)                 # the route the timed loop runs (ld_unet_forward_pair)
             cls = c if cls is None else {k: (cls[k][0] + v[0], v[1], v[2]) for k, v in c.items()}
             for name, (msv, fl, nl) in unet.profile_kernels().items():
                 a = agg.get(name, (0.0, fl, nl))
@@ -393,6 +393,8 @@ def main():
                    "parallelism": f"dp{world} (replicas, RCCL cond broadcast)", "hip_graph": not args.no_graph,
                    "setup_before_warmup": None if args.no_prime else "hipGraph capture + one untimed schedule pass per workload",
                    "library_sha256_16": my_lib,
+                   "cfg_pair": "ld_unet_forward_pair: the layers in front of the first cross-attention are evaluated once for the [uncond, cond] halves "
+                               "of a step (same latents); step_tflops counts the FLOPs that are executed",
                    "timed_loop": "lightdiffusion_amd.sampling.sample (product call surface)"},
         "unet_evals_per_s": head["unet_evals_per_s"],
         "step_tflops": head["step_tflops"], "mfma_frac_whole_step": head["mfma_frac_whole_step"],

@@ -70,10 +70,19 @@ int ld_unet_set_context(ld_unet* u, const void* ctx, int dtype, int n, int token
 /* x, out: [n][in_channels][h][w] fp32 NCHW; sigma: [n] fp32 (sigma, not t).  out = denoised = x - eps * sigma.
  * eps_only != 0 writes the raw UNet output (fp32 of the fp16 eps) instead. */
 int ld_unet_forward(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, void* stream);
+/* Classifier-free-guidance pair — what the reference's calc_cond_batch feeds the model every step: cat([x, x]) against cat([uncond, cond]) (LD.py:2515-2547).
+ * x: [nb][in_channels][h][w], sigma: [nb]; the resident context has 2 nb rows ([uncond x nb ; cond x nb]); out: [2 nb][..] denoised, same order.
+ * Same result as ld_unet_forward on the duplicated inputs; the layers in front of the first cross-attention (conv_in, the first ResBlock, the first
+ * transformer's GroupNorm / proj_in / self-attention) see identical inputs in both halves and are evaluated ONCE, their outputs copied (exact; per sample
+ * the bits can differ from ld_unet_forward where a contraction's tile / split choice follows the row count). */
+int ld_unet_forward_pair(ld_unet* u, const float* x, const float* sigma, float* out, int nb, int h, int w, void* stream);
 /* one forward with a HIP-event pair around every launch (recorded on `stream`), summed per kernel class:
  * 0 conv3x3 (implicit GEMM)  1 linear / 1x1 GEMM  2 attention  3 GroupNorm  4 LayerNorm  5 misc.  Synchronises the stream. */
 int ld_unet_profile(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, void* stream, double ms[6],
                     double flops[6], int launches[6]);
+/* the same for ld_unet_forward_pair (x, sigma: nb samples; out: 2 nb) */
+int ld_unet_profile_pair(ld_unet* u, const float* x, const float* sigma, float* out, int nb, int h, int w, void* stream, double ms[6],
+                         double flops[6], int launches[6]);
 /* per kernel INSTANTIATION (the names rocprofv3 --kernel-trace lists, abbreviated) of the last ld_unet_profile call:
  * one text line "name<TAB>launches<TAB>total ms<TAB>algorithmic FLOPs" each, NUL-terminated.  LD_ERR_ARG if buf is too small. */
 int ld_unet_profile_kernels(const ld_unet* u, char* buf, size_t buf_bytes);

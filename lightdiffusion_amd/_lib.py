@@ -51,6 +51,8 @@ SIGNATURES = {
     "ld_unet_weight_bytes": (_Z, [_P]),
     "ld_unet_set_context": (_I, [_P, _P, _I, _I, _I, _P]),
     "ld_unet_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ld_unet_forward_pair": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "ld_unet_profile_pair": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I)]),
     "ld_unet_profile": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_I)]),
     "ld_unet_profile_kernels": (_I, [_P, C.c_char_p, _Z]),
     "ld_unet_profile_launches": (_I, [_P, C.c_char_p, _Z]),

@@ -68,7 +68,7 @@ struct ld_unet {
     half_t* ctx16 = nullptr;
     std::vector<half_t*> ctx_k, ctx_vt;
     int ctx_n = 0, ctx_tok = 0, ctx_tpad = 0;
-    int plan_n = 0, plan_h = 0, plan_w = 0;   // last shape validated against the reserved arena
+    int plan_n = 0, plan_h = 0, plan_w = 0, plan_pair = 0;   // last shape (and route) validated against the reserved arena
     int last_launches = 0;
     double last_flops = 0.0;
     Timing timing;
@@ -252,9 +252,22 @@ int build(ld_unet* u) {
 struct Run {
     ld_unet* u;
     Exec ex;
-    int n;
-    const half_t* emb_all;   // [n][emb_total]
+    int n;                   // samples the kernels run on
+    int n_alloc = 0;         // samples every tensor is SIZED for (= n, except in front of the first cross-attention of a CFG pair)
+    bool pair_pending = false;   // CFG pair (ld_unet_forward_pair): the layers in front of the first cross-attention see the same input in the uncond and
+                                 // the cond half of the batch, so they run ONCE on n = n_alloc / 2 samples and their results are copied into the second half
+    const half_t* emb_all;   // [n_alloc][emb_total]
     half_t* P(int slot) const { return u->pt.ptr(slot); }
+    int na() const { return n_alloc > 0 ? n_alloc : n; }
+    // first half of a [2 * half_bytes] tensor -> its second half (a memcpy node of the step's hipGraph)
+    void dup(void* base, size_t half_bytes) {
+        ex.launches += 1;
+        ex.t_begin(KC_MISC, 0.0, 1, "dup", (long long)half_bytes, 0, 0, 1);
+        if (!ex.dry && ex.status == LD_OK &&
+            hipMemcpyAsync(static_cast<char*>(base) + half_bytes, base, half_bytes, hipMemcpyDeviceToDevice, ex.stream) != hipSuccess)
+            ex.note(LD_ERR_HIP);
+        ex.t_end("hipMemcpyAsync(pair)");
+    }
 
     half_t* conv3(const half_t* x1, int C1, const half_t* x2, int C2, int Hs, int Ws, int Hv, int Wv, int stride, int wslot, int bslot,
                   int cout, const half_t* rowvec, int ldrv, const half_t* R, half_t* out, int* Ho_, int* Wo_, int ksize = 3) {
@@ -291,7 +304,7 @@ struct Run {
     // ResBlock1._forward, LD.py:5273-5287.  Input = channel concat of (x1,C1) and (x2,C2).
     Feat resblock(const ResW& r, const half_t* x1, int C1, const half_t* x2, int C2, int H, int W) {
         Arena& ar = *ex.arena;
-        const size_t M = (size_t)n * H * W;
+        const size_t M = (size_t)na() * H * W;                   // rows the tensors are sized for (the kernels run on n * H * W)
         half_t* out = ar.halfs(M * r.cout);
         const size_t mk = ar.mark();
         // in_layers: GroupNorm + SiLU + conv3x3 (+ the time-embedding row vector); out_layers: GroupNorm + SiLU + conv3x3 (+ skip).
@@ -314,7 +327,7 @@ struct Run {
         half_t* g1 = ar.halfs(M * r.cin);
         half_t* h1 = ar.halfs(M * r.cout);
         // the GroupNorm statistics of h1 (out_layers' norm) come from conv1's split-K second pass where it has one (gemm.h gn_part)
-        float* gnp = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(n, H * W)));
+        float* gnp = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(na(), H * W)));
         int gnp_done = 0;
         {
             GemmParams c1 = conv_params(x1, C1, x2, C2, r.c1_w, r.c1_b, emb_all + r.emb_off, u->emb_total, nullptr, h1);
@@ -343,23 +356,24 @@ struct Run {
     Feat transformer(const StW& s, const half_t* x, int H, int W) {
         Arena& ar = *ex.arena;
         const int C = s.c, L = H * W, heads = u->cfg.num_heads, d = C / heads;
-        const int M = n * L;
-        half_t* out = ar.halfs((size_t)M * C);
+        int M = n * L;                                           // rows the kernels run on (doubles at the split of a CFG pair, below)
+        const size_t Ma = (size_t)na() * L;                      // rows the tensors are sized for
+        half_t* out = ar.halfs(Ma * C);
         const size_t mk = ar.mark();
-        half_t* g = ar.halfs((size_t)M * C);
+        half_t* g = ar.halfs(Ma * C);
         ex.groupnorm(x, C, nullptr, 0, n, L, P(s.gn_g), P(s.gn_b), 1e-6f, 0, g);
-        half_t* t = ar.halfs((size_t)M * C);
+        half_t* t = ar.halfs(Ma * C);
         const int Lp = (L + 7) & ~7;   // V^T rows are padded to 8 keys (16-byte row copies in the attention kernel)
         half_t* nrm = g;               // reuse (only the un-folded path materialises LN(x))
-        half_t* qk = ar.halfs((size_t)M * 2 * C);
-        half_t* vt = ar.halfs((size_t)n * C * Lp);
-        half_t* ao = ar.halfs((size_t)M * C);
+        half_t* qk = ar.halfs(Ma * 2 * C);
+        half_t* vt = ar.halfs((size_t)na() * C * Lp);
+        half_t* ao = ar.halfs(Ma * C);
         half_t* ff = nullptr;
         const bool fold = u->ln_fold;
         // LN fold: the three LayerNorms disappear into the GEMMs around them.  The GEMM that WRITES the residual stream t also
         // writes per-row (sum, sum of squares) partials of t (one pair per N tile); the projections that read LN(t) run on t itself
         // with gamma folded into their weights and finish  rstd * (acc - mu * wsum) + b'  in the epilogue (gemm.h).
-        float* stat = fold ? reinterpret_cast<float*>(ar.alloc((size_t)((C + 63) / 64) * M * 2 * sizeof(float))) : nullptr;
+        float* stat = fold ? reinterpret_cast<float*>(ar.alloc((size_t)((C + 63) / 64) * Ma * 2 * sizeof(float))) : nullptr;
         int parts = 0;
         char* fb = u->fold_base;
         auto producer = [&](const half_t* x_, int lda, int wslot, int bslot, const half_t* R, int K) {   // t = x_ W^T + b (+ R), with row stats
@@ -420,6 +434,19 @@ struct Run {
             a.scale = 1.0f / sqrtf((float)d);
             ex.attention(a);
         }
+        if (pair_pending) {
+            // CFG pair: everything up to here saw the same input in both halves of the batch and ran on the first half only.  The cross-attention
+            // below is the first operation that reads the conditioning: copy the residual stream t, the self-attention output and the block's
+            // input (its residual at the end) into the second half and carry on with all n_alloc samples.  (The out-projection of attn1 runs on
+            // both halves: its LayerNorm-fold statistics are laid out by the row count of the GEMM that writes them.)
+            const size_t hb = (size_t)M * C * sizeof(half_t);
+            dup(t, hb);
+            dup(ao, hb);
+            dup(const_cast<half_t*>(x), hb);
+            pair_pending = false;
+            n = n_alloc;
+            M = n * L;
+        }
         producer(ao, C, s.o1_w, s.o1_b, t, C);
         // ---- cross attention against the hoisted context K / V^T
         if (!fold) ex.layernorm(t, P(s.ln2_g), P(s.ln2_b), nrm, M, C);
@@ -450,7 +477,7 @@ struct Run {
         producer(ao, C, s.o2_w, s.o2_b, t, C);
         // ---- GEGLU feed-forward: x = ff2(a * gelu(gate)) + x
         if (!fold) ex.layernorm(t, P(s.ln3_g), P(s.ln3_b), nrm, M, C);
-        ff = ar.halfs((size_t)M * 4 * C);
+        ff = ar.halfs(Ma * 4 * C);
         {
             GemmParams p;
             p.A = fold ? t : nrm; p.lda = C;
@@ -507,15 +534,20 @@ int fold_layernorms(ld_unet* u, hipStream_t stream) {
     return LD_OK;
 }
 
+// `pair`: classifier-free-guidance pair (ld_unet_forward_pair).  x / sigma hold n / 2 samples; the batch is [uncond x n/2 ; cond x n/2] of the SAME latents
+// (what calc_cond_batch feeds the model: cat([x, x]), LD.py:2515-2547); the resident context has n rows.  The layers in front of the first
+// cross-attention run once on n / 2 samples (Run::pair_pending), everything else on n.  out: n samples.
 int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, hipStream_t stream,
-                size_t* dry_peak = nullptr) {
+                size_t* dry_peak = nullptr, bool pair = false) {
     if (!dry && u->ln_fold && u->fold_dirty) {
         const int st = fold_layernorms(u, stream);
         if (st != LD_OK) return st;
     }
+    if (pair && (n & 1)) return LD_ERR_SHAPE;
     Run R;
     R.u = u;
     R.n = n;
+    R.n_alloc = n;
     Exec& ex = R.ex;
     ex.stream = stream;
     ex.dry = dry;
@@ -531,6 +563,24 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
     ar.release(0);
     const ld_unet_config& c = u->cfg;
     const int mc = c.model_channels, ted = u->ted;
+    if (pair) {
+        // both halves of the inputs side by side (the output convolution and the time embedding index them by sample): 2 x 2 small copies
+        const int nb = n / 2;
+        float* x2 = reinterpret_cast<float*>(ar.alloc((size_t)n * c.in_channels * h * w * sizeof(float)));
+        float* s2 = reinterpret_cast<float*>(ar.alloc((size_t)n * sizeof(float)));
+        const size_t xb = (size_t)nb * c.in_channels * h * w * sizeof(float), sb = (size_t)nb * sizeof(float);
+        ex.launches += 2;
+        ex.t_begin(KC_MISC, 0.0, 2, "dup_in", (long long)xb, 0, 0, 1);
+        if (!dry && (hipMemcpyAsync(x2, x, xb, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+                     hipMemcpyAsync(s2, sigma, sb, hipMemcpyDeviceToDevice, stream) != hipSuccess))
+            ex.note(LD_ERR_HIP);
+        ex.t_end("hipMemcpyAsync(pair)");
+        R.dup(x2, xb);
+        R.dup(s2, sb);
+        x = x2;
+        sigma = s2;
+        R.pair_pending = true;
+    }
 
     // timestep embedding -> time_embed MLP -> all ResBlock emb_layers at once (every consumer applies SiLU first)
     half_t* temb = ar.halfs((size_t)n * mc);
@@ -559,6 +609,11 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
                 case L_DOWN: {
                     const ConvW& cw = u->convs[L.idx];
                     const int Ho = (f.H - 1) / 2 + 1, Wo = (f.W - 1) / 2 + 1;
+                    if (R.pair_pending) {                         // (not in front of the first transformer of any supported layout; be safe)
+                        R.dup(const_cast<half_t*>(f.p), (size_t)R.n * f.H * f.W * f.C * sizeof(half_t));
+                        R.pair_pending = false;
+                        R.n = n;
+                    }
                     half_t* o = ar.halfs((size_t)n * Ho * Wo * cw.cout);
                     R.conv3(f.p, f.C, nullptr, 0, f.H, f.W, f.H, f.W, 2, cw.w, cw.b, cw.cout, nullptr, 0, nullptr, o, nullptr, nullptr);
                     f = {o, cw.cout, Ho, Wo};
@@ -583,20 +638,31 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
     {   // input_blocks[0]: conv_in fused with EPS.calculate_input and the fp32 NCHW -> fp16 NHWC layout change
         const ConvW& cw = u->convs[u->in_blocks[0][0].idx];
         half_t* o = ar.halfs((size_t)n * h * w * mc);
+        if (R.pair_pending) R.n = n / 2;                          // the shared prefix runs on the first half (see Run::pair_pending)
         SmallConvInArgs a;
         a.x = x; a.scale_sigma = sigma; a.w = u->pt.ptr(cw.w); a.b = u->pt.ptr(cw.b); a.y = o;
-        a.N = n; a.Cin = c.in_channels; a.H = h; a.W = w; a.Cout = mc;
+        a.N = R.n; a.Cin = c.in_channels; a.H = h; a.W = w; a.Cout = mc;
         ex.launches += 1;
-        ex.flops += 2.0 * n * h * w * mc * 9.0 * c.in_channels;
-        ex.t_begin(KC_MISC, 2.0 * n * h * w * mc * 9.0 * c.in_channels, 1);
+        ex.flops += 2.0 * R.n * h * w * mc * 9.0 * c.in_channels;
+        ex.t_begin(KC_MISC, 2.0 * R.n * h * w * mc * 9.0 * c.in_channels, 1);
         if (!dry) ex.note(small_conv_in_launch(a, stream));
         ex.t_end("small_conv_in_kernel");
+        if (R.pair_pending) R.dup(o, (size_t)R.n * h * w * mc * sizeof(half_t));   // a skip connection: read by the last output block on all n samples
         f = {o, mc, h, w};
         hs.push_back(f);
     }
     for (size_t b = 1; b < u->in_blocks.size(); ++b) {
         f = run_layers(u->in_blocks[b], f, nullptr, 0, 0, 0);
+        if (R.pair_pending && b == 1) {                          // no transformer in the first block: its output is the last shared tensor
+            R.dup(const_cast<half_t*>(f.p), (size_t)R.n * f.H * f.W * f.C * sizeof(half_t));
+            R.pair_pending = false;
+            R.n = n;
+        }
         hs.push_back(f);
+    }
+    if (R.pair_pending) {                                        // (a UNet without input blocks: nothing left to share)
+        R.pair_pending = false;
+        R.n = n;
     }
     f = run_layers(u->mid_block, f, nullptr, 0, 0, 0);
     for (size_t b = 0; b < u->out_blocks.size(); ++b) {
@@ -707,7 +773,7 @@ int ld_unet_reserve(ld_unet* u, int max_n, int max_h, int max_w, int max_tok) {
     }
     // plan: dry-run the executor to find the activation peak
     u->arena = Arena();
-    u->plan_n = u->plan_h = u->plan_w = 0;
+    u->plan_n = u->plan_h = u->plan_w = u->plan_pair = 0;
     u->ctx_tok = max_tok;
     u->ctx_tpad = (max_tok + 7) & ~7;
     u->ctx_k.assign(u->st.size(), nullptr);
@@ -715,6 +781,12 @@ int ld_unet_reserve(ld_unet* u, int max_n, int max_h, int max_w, int max_tok) {
     size_t peak = 0;
     int st = run_forward(u, true, nullptr, nullptr, nullptr, max_n, max_h, max_w, 0, nullptr, &peak);
     if (st != LD_OK) return st;
+    if (!(max_n & 1)) {   // the CFG-pair route (ld_unet_forward_pair) keeps the duplicated inputs in the arena as well
+        size_t peak2 = 0;
+        st = run_forward(u, true, nullptr, nullptr, nullptr, max_n, max_h, max_w, 0, nullptr, &peak2, true);
+        if (st != LD_OK) return st;
+        if (peak2 > peak) peak = peak2;
+    }
     const size_t act = (peak + 4095) / 4096 * 4096;
     const size_t tpad = (size_t)u->ctx_tpad;
     size_t ctxb = ((size_t)max_n * tpad * u->cfg.context_dim * sizeof(half_t) + 255) / 256 * 256;
@@ -780,29 +852,52 @@ int ld_unet_set_context(ld_unet* u, const void* ctx, int dtype, int n, int token
     return LD_OK;
 }
 
-int ld_unet_forward(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, void* stream) {
+static int forward_checked(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, void* stream, bool pair) {
     if (u == nullptr || x == nullptr || sigma == nullptr || out == nullptr) return LD_ERR_ARG;
     if (u->ws_base == nullptr || !u->pt.all_loaded() || u->ctx_n == 0) return LD_ERR_STATE;
     if (n != u->ctx_n) return LD_ERR_SHAPE;
     if (n > u->max_n || h < 1 || w < 1) return LD_ERR_SHAPE;
     int st = LD_OK;
-    if (n != u->plan_n || h != u->plan_h || w != u->plan_w) {   // new shape: plan it on the host before touching the GPU
+    if (n != u->plan_n || h != u->plan_h || w != u->plan_w || (int)pair != u->plan_pair) {   // new shape: plan it on the host before touching the GPU
         size_t peak = 0;
-        st = run_forward(u, true, nullptr, nullptr, nullptr, n, h, w, eps_only, nullptr, &peak);
+        st = run_forward(u, true, nullptr, nullptr, nullptr, n, h, w, eps_only, nullptr, &peak, pair);
         if (st != LD_OK) return st;
         if (peak > u->arena.cap) return LD_ERR_SHAPE;
         u->plan_n = n;
         u->plan_h = h;
         u->plan_w = w;
+        u->plan_pair = (int)pair;
     }
-    return run_forward(u, false, x, sigma, out, n, h, w, eps_only, (hipStream_t)stream);
+    return run_forward(u, false, x, sigma, out, n, h, w, eps_only, (hipStream_t)stream, nullptr, pair);
 }
+
+int ld_unet_forward(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, void* stream) {
+    return forward_checked(u, x, sigma, out, n, h, w, eps_only, stream, false);
+}
+
+int ld_unet_forward_pair(ld_unet* u, const float* x, const float* sigma, float* out, int nb, int h, int w, void* stream) {
+    if (nb < 1) return LD_ERR_SHAPE;
+    return forward_checked(u, x, sigma, out, 2 * nb, h, w, 0, stream, true);
+}
+
+static int profile_any(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, void* stream, double ms[6], double flops[6],
+                       int launches[6], bool pair);
 
 int ld_unet_profile(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, void* stream, double ms[6],
                     double flops[6], int launches[6]) {
+    return profile_any(u, x, sigma, out, n, h, w, stream, ms, flops, launches, false);
+}
+
+int ld_unet_profile_pair(ld_unet* u, const float* x, const float* sigma, float* out, int nb, int h, int w, void* stream, double ms[6],
+                         double flops[6], int launches[6]) {
+    return profile_any(u, x, sigma, out, 2 * nb, h, w, stream, ms, flops, launches, true);
+}
+
+static int profile_any(ld_unet* u, const float* x, const float* sigma, float* out, int n, int h, int w, void* stream, double ms[6], double flops[6],
+                       int launches[6], bool pair) {
     if (u == nullptr || ms == nullptr || flops == nullptr || launches == nullptr) return LD_ERR_ARG;
     u->want_timing = true;
-    int st = ld_unet_forward(u, x, sigma, out, n, h, w, 0, stream);
+    int st = forward_checked(u, x, sigma, out, n, h, w, 0, stream, pair);
     u->want_timing = false;
     if (st != LD_OK) return st;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return LD_ERR_HIP;

@@ -1,9 +1,11 @@
 """Step-level runtime: the classifier-free-guided denoiser of one sampler step as a replayable hipGraph.
 
 One sampler step of the reference = `sampling_function` (LD.py:2609-2626): cat([x, x]) → UNet on N = 2B samples in
-the order [uncond, cond] → uncond + (cond - uncond) * cfg.  Here the 2B-sample input, sigma and output live in static
-device buffers, the ~370 kernel launches of the forward plus the guidance mix are captured once into a hipGraph and
-replayed per step (sigma is read from device memory, so one graph serves every step).
+the order [uncond, cond] → uncond + (cond - uncond) * cfg.  Here the B-sample input, sigma and the 2B-sample output live in
+static device buffers, the ~345 kernel launches of the forward plus the guidance mix are captured once into a hipGraph and
+replayed per step (sigma is read from device memory, so one graph serves every step).  The forward is the library's CFG-pair
+entry (`ld_unet_forward_pair`): both halves of the batch are the SAME latents, so the layers in front of the first
+cross-attention — conv_in, the first ResBlock, the first transformer's self-attention — are evaluated once.
 """
 from __future__ import annotations
 
@@ -20,9 +22,9 @@ class CFGDenoiser:
         self.unet, self.batch, self.cfg_scale = unet, batch, float(cfg_scale)
         dev = unet.device
         c = unet.cfg["in_channels"]
-        self.x2 = torch.zeros(2 * batch, c, h, w, dtype=torch.float32, device=dev)
-        self.sigma2 = torch.ones(2 * batch, dtype=torch.float32, device=dev)
-        self.den2 = torch.zeros_like(self.x2)
+        self.x1 = torch.zeros(batch, c, h, w, dtype=torch.float32, device=dev)
+        self.sigma1 = torch.ones(batch, dtype=torch.float32, device=dev)
+        self.den2 = torch.zeros(2 * batch, c, h, w, dtype=torch.float32, device=dev)
         self.den = torch.zeros(batch, c, h, w, dtype=torch.float32, device=dev)
         self.use_graph = use_graph
         self._graph: Optional[torch.cuda.CUDAGraph] = None
@@ -34,7 +36,7 @@ class CFGDenoiser:
         self.unet.set_context(torch.cat([rep(uncond), rep(cond)]).contiguous())
 
     def _body(self) -> None:
-        self.unet.forward(self.x2, self.sigma2, out=self.den2)
+        self.unet.forward_pair(self.x1, self.sigma1, out=self.den2)
         from ._lib import check, lib
         check(lib().ld_op_cfg_combine(self.den2.data_ptr(), self.den.data_ptr(), self.cfg_scale, self.den.numel(),
                                       torch.cuda.current_stream().cuda_stream), "ld_op_cfg_combine")
@@ -69,17 +71,12 @@ class CFGDenoiser:
     def run(self, x: torch.Tensor, timestep: torch.Tensor) -> torch.Tensor:
         """x [B,C,h,w] fp32, timestep [B] fp32 (sigma per sample), both on the device: no host read, so the host runs ahead
         of the GPU across steps.  Returns the static output buffer (valid until the next call)."""
-        b = self.batch
-        self.x2[:b].copy_(x)
-        self.x2[b:].copy_(x)
-        self.sigma2[:b].copy_(timestep)
-        self.sigma2[b:].copy_(timestep)
+        self.x1.copy_(x)
+        self.sigma1.copy_(timestep)
         return self._launch()
 
     def __call__(self, x: torch.Tensor, sigma: float) -> torch.Tensor:
         """x [B,C,h,w] fp32 on the device, sigma a host scalar -> guided denoised x0 [B,C,h,w] (static buffer)."""
-        b = self.batch
-        self.x2[:b].copy_(x)
-        self.x2[b:].copy_(x)
-        self.sigma2.fill_(float(sigma))
+        self.x1.copy_(x)
+        self.sigma1.fill_(float(sigma))
         return self._launch()

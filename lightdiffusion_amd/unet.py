@@ -164,6 +164,22 @@ class MI355XUNet:
                   "ld_unet_forward")
         return out
 
+    def forward_pair(self, x: torch.Tensor, sigma: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The classifier-free-guidance pair of one sampler step (calc_cond_batch's cat([x, x]) against cat([uncond, cond]), LD.py:2515-2547):
+        x [B,4,h,w], sigma [B] -> denoised [2B,4,h,w] in the order [uncond.., cond..] of the resident 2B-row context.  The layers in front of
+        the first cross-attention are evaluated once for both halves (`ld_unet_forward_pair`)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        assert sigma.is_cuda and sigma.dtype == torch.float32 and sigma.is_contiguous()
+        b, c, h, w = x.shape
+        if out is None:
+            out = torch.empty(2 * b, c, h, w, dtype=torch.float32, device=x.device)
+        mn, mh, mw, _ = self._reserved
+        if 2 * b > mn or h > mh or w > mw:
+            raise LDError(ERR_SHAPE, f"ld_unet_forward_pair: input 2x{b}x{h}x{w} exceeds the reserved plan {mn}x{mh}x{mw} (reserve(), then set_context)")
+        with torch.cuda.device(self.device):
+            check(lib().ld_unet_forward_pair(self._h, x.data_ptr(), sigma.data_ptr(), out.data_ptr(), b, h, w, _stream()), "ld_unet_forward_pair")
+        return out
+
     KERNEL_CLASSES = ("conv3x3", "gemm", "attention", "groupnorm", "layernorm", "misc")
 
     def profile(self, x: torch.Tensor, sigma: torch.Tensor) -> dict:
@@ -174,6 +190,16 @@ class MI355XUNet:
         with torch.cuda.device(self.device):
             check(lib().ld_unet_profile(self._h, x.data_ptr(), sigma.data_ptr(), out.data_ptr(), n, h, w, _stream(), ms, fl, nl),
                   "ld_unet_profile")
+        return {k: (ms[i], fl[i], nl[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
+
+    def profile_pair(self, x: torch.Tensor, sigma: torch.Tensor) -> dict:
+        """`profile` of the CFG-pair route (`forward_pair`): x [B,..], sigma [B]."""
+        b, c, h, w = x.shape
+        out = torch.empty(2 * b, c, h, w, dtype=torch.float32, device=x.device)
+        ms, fl, nl = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_int * 6)()
+        with torch.cuda.device(self.device):
+            check(lib().ld_unet_profile_pair(self._h, x.data_ptr(), sigma.data_ptr(), out.data_ptr(), b, h, w, _stream(), ms, fl, nl),
+                  "ld_unet_profile_pair")
         return {k: (ms[i], fl[i], nl[i]) for i, k in enumerate(self.KERNEL_CLASSES)}
 
     def profile_kernels(self) -> dict:

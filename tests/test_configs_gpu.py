@@ -300,7 +300,8 @@ def tiny_stack():
 
 def test_ksampler_graph_equals_eager_bitwise(tiny_stack):
     """`KSampler2.sample -> common_ksampler -> CFGGuider -> sampling_function` replays a hipGraph (what bench.py times);
-    the same call with the graph off, and with the un-fused wrapper-hook route, must give bit-identical latents."""
+    the same call with the graph off must give bit-identical latents.  The un-fused wrapper-hook route runs the plain forward on cat([x, x])
+    where the product path runs the CFG-pair forward (shared layers evaluated once): the same latents up to tile / split rounding."""
     from lightdiffusion_amd import nodes
     model = tiny_stack[0]
     g = load_golden("samplers")
@@ -315,7 +316,8 @@ def test_ksampler_graph_equals_eager_bitwise(tiny_stack):
     unet = model.model.diffusion_model
     assert any(d._graph is not None for d in unet._denoisers.values()), "the product path did not capture a graph"
     for k in ("", "_2m"):
-        assert torch.equal(outs["graph" + k], outs["eager" + k]) and torch.equal(outs["graph" + k], outs["hook" + k])
+        assert torch.equal(outs["graph" + k], outs["eager" + k])
+        assert rel_l2(outs["graph" + k], outs["hook" + k]) < 5e-3
     assert torch.isfinite(outs["graph"]).all() and not torch.equal(outs["graph"][0], outs["graph"][1])
 
 

@@ -48,6 +48,39 @@ def test_tiny_unet_batch4_matches_batch2(tiny_unet):
     assert torch.equal(d2, d2b), "same inputs, same shape: the step must be bitwise reproducible"
 
 
+def test_forward_pair_equals_forward_on_duplicated_inputs(tiny_unet):
+    """`ld_unet_forward_pair` (the CFG pair of a sampler step: the layers in front of the first cross-attention evaluated once for both halves)
+    against `ld_unet_forward` on cat([x, x]) — the same rows up to the rounding of tile / split choices that follow the row count — for the tiny
+    net at B = 1 / 2 (two contexts per sample: the halves must differ) and, below, for the SD1.5 net against the reference golden."""
+    g = load_golden("unet_tiny_16x16")
+    gen = torch.Generator().manual_seed(5)
+    for b in (1, 2):
+        x = (torch.randn(b, 4, 16, 16, generator=gen) * 3.0).to(DEV)
+        s = torch.tensor([2.5, 0.7][:b], device=DEV)
+        ctx = torch.randn(2 * b, 77, g["ctx"].shape[-1], generator=gen)
+        tiny_unet.set_context(ctx)
+        full = tiny_unet.forward(torch.cat([x, x]).contiguous(), torch.cat([s, s]).contiguous()).cpu()
+        pair = tiny_unet.forward_pair(x, s).cpu()
+        assert pair.shape == full.shape and rel_l2(pair, full) < 1e-3, (b, rel_l2(pair, full))
+        assert not torch.equal(pair[:b], pair[b:])                   # the cond half really saw the other context
+        assert torch.equal(pair, tiny_unet.forward_pair(x, s).cpu())   # bitwise reproducible
+        assert tiny_unet.last_launches > 0
+
+
+def test_sd15_forward_pair_against_reference_golden():
+    """SD1.5 net: the golden's two samples carry different x, so each is run as its own CFG pair (x_i twice, contexts [ctx_j, ctx_i]): the cond half
+    of pair i must be the reference's denoised row i."""
+    from lightdiffusion_amd.unet import synthetic_unet
+    g = load_golden("unet_sd15_64x64")
+    u = synthetic_unet(W.sd15_unet_config(), max_batch=2, max_hw=(64, 64))
+    for i in (0, 1):
+        u.set_context(torch.stack([g["ctx"][1 - i], g["ctx"][i]]))
+        den = u.forward_pair(g["x"][i:i + 1].to(DEV).contiguous(), g["sigma"][i:i + 1].to(DEV).contiguous()).cpu()
+        assert rel_l2(den[1], g["denoised"][i]) < UNET_TOL
+    del u
+    torch.cuda.empty_cache()
+
+
 def test_wrapper_hook_contract(tiny_unet):
     """Drive the object exactly as calc_cond_batch does (LD.py:2558-2567) with the recorded hook arguments."""
     g = load_golden("samplers")

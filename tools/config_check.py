@@ -27,5 +27,5 @@ d.set_context(torch.randn(1, 77, 768), torch.randn(1, 77, 768))
 x = torch.randn(4, 4, 128, 128, device='cuda') * 1.3
 dt = t(lambda: d(x, 1.2768))
 print(f"hires UNet CFG step b=4 128x128 latents: {dt*1e3:8.2f} ms/step  {1/dt:6.2f} steps/s  {unet.last_flops/dt/1e12:7.1f} TF/s finite={bool(torch.isfinite(d.den).all())}", flush=True)
-p = unet.profile(d.x2, d.sigma2)
+p = unet.profile_pair(d.x1, d.sigma1)
 print({k: round(v[0], 2) for k, v in p.items()})
