@@ -67,6 +67,26 @@ def test_forward_pair_equals_forward_on_duplicated_inputs(tiny_unet):
         assert tiny_unet.last_launches > 0
 
 
+def test_forward_pair_without_a_transformer_in_the_first_block():
+    """A layout whose first input block has no SpatialTransformer (transformer_depth[0] = 0): the shared part of a CFG pair then ends at that
+    block's output (the first cross-attention sits in a later block)."""
+    from lightdiffusion_amd.unet import synthetic_unet
+    cfg = dict(W.tiny_unet_config(), transformer_depth=[0, 1, 1, 1, 1, 1, 0, 0])
+    u = synthetic_unet(cfg, max_batch=4, max_hw=(16, 16))
+    gen = torch.Generator().manual_seed(6)
+    x = (torch.randn(2, 4, 16, 12, generator=gen) * 3.0).to(DEV)
+    s = torch.tensor([2.5, 0.7], device=DEV)
+    u.set_context(torch.randn(4, 77, cfg["context_dim"], generator=gen))
+    full = u.forward(torch.cat([x, x]).contiguous(), torch.cat([s, s]).contiguous()).cpu()
+    pair = u.forward_pair(x, s).cpu()
+    assert rel_l2(pair, full) < 1e-3 and not torch.equal(pair[:2], pair[2:])
+    ctx = torch.randn(4, 77, cfg["context_dim"], generator=torch.Generator().manual_seed(7))
+    u.set_context(ctx)
+    pair = u.forward_pair(x, s).cpu()
+    ref = O.apply_model(W.synth_state_dict(W.unet_param_shapes(cfg)), cfg, O.ModelSampling(), torch.cat([x, x]).cpu(), torch.cat([s, s]).cpu(), ctx)
+    assert rel_l2(pair, ref) < UNET_TOL
+
+
 def test_sd15_forward_pair_against_reference_golden():
     """SD1.5 net: the golden's two samples carry different x, so each is run as its own CFG pair (x_i twice, contexts [ctx_j, ctx_i]): the cond half
     of pair i must be the reference's denoised row i."""
