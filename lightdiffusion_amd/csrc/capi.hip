@@ -82,13 +82,23 @@ int ld_op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int
     p.C = (half_t*)y; p.ldc = cout;
     p.partial = (float*)ws;
     p.partial_bytes = ws ? ws_bytes : 0;
+    if (ws != nullptr && ws_bytes > ((size_t)8 << 20)) {   // the head of a roomy scratch buffer doubles as the (zeroed) counters of the in-launch reductions
+        GemmParams c8 = p;
+        c8.sync = (int*)ws;
+        c8.partial = (float*)((char*)ws + 1024);
+        c8.partial_bytes = ws_bytes - 1024;
+        if (conv8_plan(c8, nullptr)) {
+            if (hipMemsetAsync(ws, 0, LD_SYNC_INTS * sizeof(int), (hipStream_t)stream) != hipSuccess) return LD_ERR_HIP;
+            return gemm_launch(c8, (hipStream_t)stream);
+        }
+    }
     return gemm_launch(p, (hipStream_t)stream);
 }
 
 size_t ld_op_groupnorm_conv_ws_bytes(int c1, int c2, int n, int h, int w, int cout) {
     const size_t C = (size_t)c1 + c2, HW = (size_t)h * w;
     return align256(groupnorm_workspace_bytes(n, (int)HW)) + 2 * align256((size_t)n * C * sizeof(float)) + align256((size_t)n * HW * C * sizeof(half_t)) +
-           ((size_t)96 << 20);
+           align256(LD_SYNC_INTS * sizeof(int)) + ((size_t)96 << 20);
 }
 
 int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int w, const void* gamma, const void* beta, float eps,
@@ -105,6 +115,7 @@ int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, 
     float* scale = (float*)q; q += align256((size_t)n * C * sizeof(float));
     float* shift = (float*)q; q += align256((size_t)n * C * sizeof(float));
     half_t* g = (half_t*)q; q += align256((size_t)n * HW * C * sizeof(half_t));
+    int* sync = (int*)q; q += align256(LD_SYNC_INTS * sizeof(int));
     GemmParams p;
     p.conv = 1; p.ksize = 3;
     p.A = (const half_t*)x1; p.A2 = (const half_t*)x2; p.C1 = c1; p.C2 = c2;
@@ -116,6 +127,18 @@ int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, 
     p.R = (const half_t*)residual; p.ldr = cout;
     p.C = (half_t*)y; p.ldc = cout;
     p.partial = (float*)q; p.partial_bytes = (size_t)96 << 20;
+    {   // row-resident kernel (conv8.hip): statistics pass, then the convolution finishes and applies the normalisation itself
+        GemmParams c8 = p;
+        c8.sync = sync;
+        c8.gn_in_part = part; c8.gn_in_P = gn_num_chunks(n, HW);
+        c8.gn_gamma = (const half_t*)gamma; c8.gn_beta = (const half_t*)beta; c8.gn_eps = eps; c8.gn_silu = 1;
+        if (conv8_plan(c8, nullptr)) {
+            if (hipMemsetAsync(sync, 0, LD_SYNC_INTS * sizeof(int), stream) != hipSuccess) return LD_ERR_HIP;   // (a caller's scratch: not known to be zero)
+            int st = groupnorm_stats_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, HW, part, stream);
+            if (st != LD_OK) return st;
+            return gemm_launch(c8, stream);
+        }
+    }
     if (gemm_conv_fuses_groupnorm(p)) {
         int st = groupnorm_scale_shift_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, HW, (const half_t*)gamma, (const half_t*)beta, eps, part,
                                               scale, shift, stream);

@@ -65,9 +65,27 @@ struct GemmParams {
     //   Honoured only when the launch splits over K (otherwise *gn_part_done stays 0 and the caller runs the statistics pass).
     float* gn_part = nullptr;          // [n_img][gn_P][32][2] floats
     int gn_P = 0, gn_ppb = 0, gn_HW = 0;
-    int* gn_part_done = nullptr;       // host int, set to 1 when the partials were written
+    int* gn_part_done = nullptr;       // host int, set to the number of pixel chunks per image of the partials that were written (0: none)
+    // ---- row-resident small-M convolution (conv8.hip): GroupNorm(+SiLU) of the INPUT applied while the activations are staged, with
+    //   scale / shift finished IN the kernel from partial statistics [n_img][gn_in_P][32][2] (gn_stats_kernel's layout, any chunk count)
+    const float* gn_in_part = nullptr;
+    int gn_in_P = 0;
+    const half_t* gn_gamma = nullptr;
+    const half_t* gn_beta = nullptr;
+    float gn_eps = 0.f;
+    //   its in-launch reduction of the channel-slab partial sums needs >= 4 * (N / 80) zeroed ints that it leaves zeroed (self-resetting)
+    int* sync = nullptr;
+    int c8_S = 0;                // (internal) slab split chosen by conv8_plan
     int dbg = 0;                 // A/B build only (LD_AB_BUILD): ablation switches of the v5 kernel (timing runs, wrong results)
 };
+
+// conv8.hip: row-resident 3x3 convolution for the two-image (batch-1 CFG pair) 16x16 / 8x8 levels.  conv8_plan: does gemm_launch run this
+// convolution there (p.partial and p.sync set)?  conv8_gn_chunks: pixel chunks per image of the GroupNorm partials it writes to gn_part
+// (also stored to *gn_part_done).
+bool conv8_plan(const GemmParams& p, int* S_out);
+int conv8_gn_chunks(const GemmParams& p);
+int conv8_launch(const GemmParams& p, hipStream_t stream);
+#define LD_SYNC_INTS 256         // ints a caller provides behind GemmParams::sync
 
 bool gemm_ln_fold_available();   // the kernels that implement stat_out / ln_stat are the ones gemm_launch will pick
 const char* gemm_last_kernel_name();   // kernel instantiation the calling thread's last gemm_launch dispatched

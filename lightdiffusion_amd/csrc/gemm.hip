@@ -2310,7 +2310,7 @@ static void launch_splitk_reduce(const GemmParams& p, int bn, hipStream_t stream
                     p.ldc == p.N && (p.N / 4) % 8 == 0 && p.N / 32 <= 256;
     if (gn) {
         hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3(p.gn_P, p.M / p.gn_HW, 4), dim3(256), 0, stream, p);
-        if (p.gn_part_done != nullptr) *p.gn_part_done = 1;
+        if (p.gn_part_done != nullptr) *p.gn_part_done = p.gn_P;
         t_last_kernel = intern_name(std::string(t_last_kernel) + "+splitk_reduce_gn_kernel");
         return;
     }
@@ -2451,6 +2451,15 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (p.R != nullptr && (p.ldr & 7)) return LD_ERR_SHAPE;
 
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
+    // ---- conv8 (row-resident, weights streamed once, in-launch slab reduction): the two-image 16x16 / 8x8 levels of a batch-1 step
+    if (conv8_plan(p, nullptr)) {
+        const bool up8 = p.Hv == 2 * p.Hs;
+        t_last_kernel = p.Wo == 16 ? (up8 ? "conv8_kernel<W16,up>" : p.gn_in_part ? "conv8_kernel<W16,groupnorm>" : "conv8_kernel<W16>")
+                                   : (up8 ? "conv8_kernel<W8,up>" : p.gn_in_part ? "conv8_kernel<W8,groupnorm>" : "conv8_kernel<W8>");
+        if (p.gn_part != nullptr && p.gn_part_done != nullptr) *p.gn_part_done = conv8_gn_chunks(p);
+        return conv8_launch(p, stream);
+    }
+    if (p.gn_in_part != nullptr) return LD_ERR_ARG;   // only conv8 finishes a GroupNorm from partial statistics (ask conv8_plan first)
     // ---- v6 (halo-tile 3x3 convolution on the v5 skeleton): stride-1 convs whose tiles are whole image rows and fill the chip
     V6Plan pl;
     if (v6_plan(p, &pl)) {

@@ -18,8 +18,12 @@ static inline int gn_num_chunks(int n_img, int HW) {
     return p < 1 ? 1 : p;
 }
 size_t groupnorm_workspace_bytes(int n_img, int HW);
+// stats_ready: 0 = run the statistics pass; > 0 = `partial` already holds a producer's partial statistics with that many pixel chunks per
+// image ([n_img][stats_ready][32][2]: gemm.h gn_part / conv8) and only the apply pass runs
 int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, const half_t* gamma,
                      const half_t* beta, float eps, int silu, half_t* y, float* partial, hipStream_t stream, int stats_ready = 0);
+// the statistics pass alone: partial [n_img][gn_num_chunks(n_img, HW)][32][2] (for a consumer that finishes the normalisation itself: conv8)
+int groupnorm_stats_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, float* partial, hipStream_t stream);
 // statistics pass + finalize only: scale / shift [n_img][C1 + C2] fp32 for a consumer that normalises on the fly (gemm.h gn_scale)
 int groupnorm_scale_shift_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, const half_t* gamma, const half_t* beta,
                                  float eps, float* partial, float* scale, float* shift, hipStream_t stream, int stats_ready = 0);

@@ -18,9 +18,10 @@ __host__ __device__ inline int gn_slabs(int C) { return C >= 256 ? 4 : C >= 128 
 struct GnArgs {
     const half_t* x1;
     const half_t* x2;
-    int C1, C2, HW, P, ppb;   // P pixel-chunks per image, ppb pixels per chunk
+    int C1, C2, HW, P, ppb;   // P pixel-chunks per image, ppb pixels per chunk (the grid of the statistics and of the apply pass)
+    int Pstat;                // chunks per image of `partial` (= P when gn_stats_kernel wrote it; a producer's epilogue may use another count)
     int slabs;                // gn_slabs(C1 + C2)
-    float* partial;           // [N][P][32][2]
+    float* partial;           // [N][Pstat][32][2]
     const half_t* gamma;
     const half_t* beta;
     half_t* y;
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
     {   // finish the statistics of this slab's groups: lpg lanes per group sweep the P partial slabs in a fixed order
         const int g = tid / lpg, sub = tid - g * lpg;
         float s = 0.f, ss = 0.f;
-        const float* pp = a.partial + ((long long)n * a.P * 32 + slab * gps + g) * 2;
-        for (int i = sub; i < a.P; i += lpg) {
+        const float* pp = a.partial + ((long long)n * a.Pstat * 32 + slab * gps + g) * 2;
+        for (int i = sub; i < a.Pstat; i += lpg) {
             s += pp[(long long)i * 64];
             ss += pp[(long long)i * 64 + 1];
         }
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(const GnArgs a,
     {
         const int g = tid / lpg, sub = tid - g * lpg;
         float s = 0.f, ss = 0.f;
-        const float* pp = a.partial + ((long long)n * a.P * 32 + slab * gps + g) * 2;
-        for (int i = sub; i < a.P; i += lpg) {
+        const float* pp = a.partial + ((long long)n * a.Pstat * 32 + slab * gps + g) * 2;
+        for (int i = sub; i < a.Pstat; i += lpg) {
             s += pp[(long long)i * 64];
             ss += pp[(long long)i * 64 + 1];
         }
@@ -303,6 +304,20 @@ size_t groupnorm_workspace_bytes(int n_img, int HW) {
     return (size_t)n_img * P * 32 * 2 * sizeof(float);
 }
 
+int groupnorm_stats_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, float* partial, hipStream_t stream) {
+    const int C = C1 + C2;
+    if (x1 == nullptr || partial == nullptr) return LD_ERR_ARG;
+    if (C % 32 || C1 % 8 || C2 % 8 || C > 8192 || C1 <= 0 || (C2 > 0 && x2 == nullptr)) return LD_ERR_SHAPE;
+    GnArgs a;
+    a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.HW = HW;
+    a.P = a.Pstat = gn_num_chunks(n_img, HW);
+    a.ppb = (HW + a.P - 1) / a.P;
+    a.partial = partial; a.gamma = nullptr; a.beta = nullptr; a.y = nullptr; a.eps = 0.f; a.silu = 0;
+    a.slabs = gn_slabs(C);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(a.P, n_img, a.slabs), dim3(GN_THREADS), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
 int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_img, int HW, const half_t* gamma,
                      const half_t* beta, float eps, int silu, half_t* y, float* partial, hipStream_t stream, int stats_ready) {
     const int C = C1 + C2;
@@ -311,6 +326,7 @@ int groupnorm_launch(const half_t* x1, int C1, const half_t* x2, int C2, int n_i
     GnArgs a;
     a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.HW = HW;
     a.P = gn_num_chunks(n_img, HW);
+    a.Pstat = stats_ready > 0 ? stats_ready : a.P;            // stats_ready: chunk count of the partials a producer wrote
     a.ppb = (HW + a.P - 1) / a.P;
     a.partial = partial; a.gamma = gamma; a.beta = beta; a.y = y; a.eps = eps; a.silu = silu;
     a.slabs = gn_slabs(C);
@@ -328,6 +344,7 @@ int groupnorm_scale_shift_launch(const half_t* x1, int C1, const half_t* x2, int
     GnArgs a;
     a.x1 = x1; a.x2 = x2; a.C1 = C1; a.C2 = C2; a.HW = HW;
     a.P = gn_num_chunks(n_img, HW);
+    a.Pstat = stats_ready > 0 ? stats_ready : a.P;
     a.ppb = (HW + a.P - 1) / a.P;
     a.partial = partial; a.gamma = gamma; a.beta = beta; a.y = nullptr; a.eps = eps; a.silu = 0;
     a.slabs = gn_slabs(C);

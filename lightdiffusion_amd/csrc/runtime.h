@@ -186,6 +186,7 @@ struct Exec {
     double flops = 0.0;
     float* splitk_ws = nullptr;
     size_t splitk_bytes = 0;
+    int* sync_ws = nullptr;          // LD_SYNC_INTS zeroed ints for the in-launch reductions (gemm.h GemmParams::sync); null: those kernels are not used
 
     void note(int st) {
         if (st != LD_OK && status == LD_OK) status = st;
@@ -221,6 +222,7 @@ struct Exec {
         if (p.batch == 1) {
             p.partial = splitk_ws;
             p.partial_bytes = splitk_bytes;
+            p.sync = sync_ws;
         }
         launches += 1;
         if (dry || status != LD_OK) return;
@@ -229,15 +231,17 @@ struct Exec {
         note(gemm_launch(p, stream));
         t_end(gemm_last_kernel_name());
     }
-    // `ready`: partial statistics the producer's split-K reduce already wrote (gemm.h gn_part): the statistics launch is skipped
+    // `ready` / `ready_P`: partial statistics the producer already wrote (gemm.h gn_part; ready_P pixel chunks per image): the statistics
+    // launch is skipped
     void groupnorm(const half_t* x1, int C1, const half_t* x2, int C2, int n, int HW, const half_t* g, const half_t* b, float eps,
-                   int silu, half_t* y, float* ready = nullptr) {
+                   int silu, half_t* y, float* ready = nullptr, int ready_P = 0) {
         const size_t m = arena->mark();
+        if (ready_P <= 0) ready = nullptr;
         float* ws = ready != nullptr ? ready : reinterpret_cast<float*>(arena->alloc(groupnorm_workspace_bytes(n, HW)));
         const int nl = ready != nullptr ? 1 : 2;
         launches += nl;
         t_begin(KC_GNORM, 0.0, nl, "groupnorm", n, HW, C1 + C2, silu);
-        if (!dry && status == LD_OK) note(groupnorm_launch(x1, C1, x2, C2, n, HW, g, b, eps, silu, y, ws, stream, ready != nullptr));
+        if (!dry && status == LD_OK) note(groupnorm_launch(x1, C1, x2, C2, n, HW, g, b, eps, silu, y, ws, stream, ready != nullptr ? ready_P : 0));
         t_end(ready != nullptr ? "gn_apply_kernel" : "gn_stats_kernel+gn_apply_kernel");
         arena->release(m);
     }
@@ -245,10 +249,32 @@ struct Exec {
     // into its A operand: only the statistics pass + a tiny finalize run here (scale / shift per image and channel), the conv reads the
     // RAW tensor(s) — no normalised copy is written or read back.  Otherwise: the two-pass GroupNorm into `g` (caller-provided), then the conv.
     // `p`: the convolution with A / A2 = the RAW sources; returns through p.C as usual.
-    // `ready`: GroupNorm partial statistics of the input that its producer already wrote (see groupnorm)
-    void gn_silu_conv(GemmParams p, int n_img, int HW, const half_t* gamma, const half_t* beta, float eps, half_t* g, float* ready = nullptr) {
+    // `ready` / `ready_P`: GroupNorm partial statistics of the input that its producer already wrote (see groupnorm)
+    void gn_silu_conv(GemmParams p, int n_img, int HW, const half_t* gamma, const half_t* beta, float eps, half_t* g, float* ready = nullptr, int ready_P = 0) {
         p.partial = splitk_ws;
         p.partial_bytes = splitk_bytes;
+        p.sync = sync_ws;
+        if (ready_P <= 0) ready = nullptr;
+        {   // row-resident kernel (conv8.hip): the normalisation is finished and applied inside the convolution from partial statistics
+            GemmParams q = p;
+            q.gn_in_part = ready != nullptr ? ready : reinterpret_cast<const float*>(p.A);   // (placeholder for the plan: any non-null pointer)
+            q.gn_in_P = ready != nullptr ? ready_P : gn_num_chunks(n_img, HW);
+            q.gn_gamma = gamma; q.gn_beta = beta; q.gn_eps = eps; q.gn_silu = 1;
+            if (conv8_plan(q, nullptr)) {
+                const size_t m = arena->mark();
+                if (ready == nullptr) {
+                    float* ws = reinterpret_cast<float*>(arena->alloc(groupnorm_workspace_bytes(n_img, HW)));
+                    launches += 1;
+                    t_begin(KC_GNORM, 0.0, 1, "gn_stats", n_img, HW, p.C1 + p.C2, 1);
+                    if (!dry && status == LD_OK) note(groupnorm_stats_launch(p.A, p.C1, p.A2, p.C2, n_img, HW, ws, stream));
+                    t_end("gn_stats_kernel");
+                    q.gn_in_part = ws;
+                }
+                gemm(q);
+                arena->release(m);
+                return;
+            }
+        }
         if (gemm_conv_fuses_groupnorm(p)) {
             const int C = p.C1 + p.C2;
             const size_t m = arena->mark();
@@ -259,7 +285,7 @@ struct Exec {
             launches += nl;
             t_begin(KC_GNORM, 0.0, nl, "gn_stats", n_img, HW, C, 1);
             if (!dry && status == LD_OK)
-                note(groupnorm_scale_shift_launch(p.A, p.C1, p.A2, p.C2, n_img, HW, gamma, beta, eps, ws, scale, shift, stream, ready != nullptr));
+                note(groupnorm_scale_shift_launch(p.A, p.C1, p.A2, p.C2, n_img, HW, gamma, beta, eps, ws, scale, shift, stream, ready != nullptr ? ready_P : 0));
             t_end(ready != nullptr ? "gn_finalize_kernel" : "gn_stats_kernel+gn_finalize_kernel");
             p.gn_scale = scale;
             p.gn_shift = shift;
@@ -268,7 +294,7 @@ struct Exec {
             arena->release(m);
             return;
         }
-        groupnorm(p.A, p.C1, p.A2, p.C2, n_img, HW, gamma, beta, eps, 1, g, ready);
+        groupnorm(p.A, p.C1, p.A2, p.C2, n_img, HW, gamma, beta, eps, 1, g, ready, ready_P);
         p.A = g;
         p.A2 = nullptr;
         p.C1 = p.C1 + p.C2;

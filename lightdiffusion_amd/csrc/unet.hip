@@ -42,6 +42,8 @@ struct Layer {
 struct Feat {
     half_t* p;
     int C, H, W;
+    float* gn = nullptr;   // GroupNorm partial statistics of this tensor, written by its producer's epilogue ([n][gnP][32][2]; gemm.h gn_part), or null
+    int gnP = 0;
 };
 
 }  // namespace
@@ -71,6 +73,7 @@ struct ld_unet {
     int plan_n = 0, plan_h = 0, plan_w = 0, plan_pair = 0;   // last shape (and route) validated against the reserved arena
     int last_launches = 0;
     double last_flops = 0.0;
+    int* sync_ws = nullptr;        // LD_SYNC_INTS zeroed ints for the in-launch reductions (gemm.h GemmParams::sync)
     Timing timing;
     bool want_timing = false;
     char* fold_base = nullptr;     // LN-folded copies of the LN-consuming projections (see StW)
@@ -269,8 +272,19 @@ struct Run {
         ex.t_end("hipMemcpyAsync(pair)");
     }
 
+    // GroupNorm partial statistics of a contraction's output (gemm.h gn_part): where the launch can emit them (its split-K second pass, or
+    // the row-resident kernel) *done receives the chunk count and the GroupNorm that follows skips its statistics launch
+    void want_stats(GemmParams& p, float* buf, int HW, int* done) {
+        p.gn_part = buf;
+        p.gn_P = gn_num_chunks(n, HW);
+        p.gn_HW = HW;
+        p.gn_ppb = (HW + p.gn_P - 1) / p.gn_P;
+        p.gn_part_done = done;
+    }
+
     half_t* conv3(const half_t* x1, int C1, const half_t* x2, int C2, int Hs, int Ws, int Hv, int Wv, int stride, int wslot, int bslot,
-                  int cout, const half_t* rowvec, int ldrv, const half_t* R, half_t* out, int* Ho_, int* Wo_, int ksize = 3) {
+                  int cout, const half_t* rowvec, int ldrv, const half_t* R, half_t* out, int* Ho_, int* Wo_, int ksize = 3, float* stats = nullptr,
+                  int* stats_done = nullptr) {
         const int Ho = ksize == 3 ? (Hv - 1) / stride + 1 : Hv, Wo = ksize == 3 ? (Wv - 1) / stride + 1 : Wv;
         GemmParams p;
         p.conv = 1;
@@ -283,6 +297,7 @@ struct Run {
         p.rowvec = rowvec; p.rows_per_vec = Ho * Wo; p.ldrv = ldrv;
         p.R = R; p.ldr = cout;
         p.C = out; p.ldc = cout;
+        if (stats != nullptr) want_stats(p, stats, Ho * Wo, stats_done);
         ex.gemm(p);
         if (Ho_) *Ho_ = Ho;
         if (Wo_) *Wo_ = Wo;
@@ -302,10 +317,14 @@ struct Run {
     }
 
     // ResBlock1._forward, LD.py:5273-5287.  Input = channel concat of (x1,C1) and (x2,C2).
-    Feat resblock(const ResW& r, const half_t* x1, int C1, const half_t* x2, int C2, int H, int W) {
+    // in_stats / in_P: GroupNorm partial statistics of x1 from its producer (only usable when there is no second source)
+    Feat resblock(const ResW& r, const half_t* x1, int C1, const half_t* x2, int C2, int H, int W, float* in_stats = nullptr, int in_P = 0) {
         Arena& ar = *ex.arena;
         const size_t M = (size_t)na() * H * W;                   // rows the tensors are sized for (the kernels run on n * H * W)
         half_t* out = ar.halfs(M * r.cout);
+        float* gno = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(na(), H * W)));   // statistics of `out` (for the next GroupNorm)
+        int gno_done = 0;
+        if (C2 != 0) in_stats = nullptr;
         const size_t mk = ar.mark();
         // in_layers: GroupNorm + SiLU + conv3x3 (+ the time-embedding row vector); out_layers: GroupNorm + SiLU + conv3x3 (+ skip).
         // Each GroupNorm is fused into its convolution's A operand where that convolution runs on the halo-tile kernel
@@ -331,12 +350,8 @@ struct Run {
         int gnp_done = 0;
         {
             GemmParams c1 = conv_params(x1, C1, x2, C2, r.c1_w, r.c1_b, emb_all + r.emb_off, u->emb_total, nullptr, h1);
-            c1.gn_part = gnp;
-            c1.gn_P = gn_num_chunks(n, H * W);
-            c1.gn_HW = H * W;
-            c1.gn_ppb = (c1.gn_HW + c1.gn_P - 1) / c1.gn_P;
-            c1.gn_part_done = &gnp_done;
-            ex.gn_silu_conv(c1, n, H * W, P(r.gn1_g), P(r.gn1_b), 1e-5f, g1);
+            want_stats(c1, gnp, H * W, &gnp_done);
+            ex.gn_silu_conv(c1, n, H * W, P(r.gn1_g), P(r.gn1_b), 1e-5f, g1, in_stats, in_P);
         }
         half_t* g2 = g1;   // g1 is dead once conv1 has consumed it (stream order); reuse when it is large enough
         if (r.cout > r.cin) g2 = ar.halfs(M * r.cout);
@@ -346,22 +361,27 @@ struct Run {
             conv3(x1, C1, x2, C2, H, W, H, W, 1, r.sk_w, r.sk_b, r.cout, nullptr, 0, nullptr, sk, nullptr, nullptr, 1);
             skip = sk;
         }
-        ex.gn_silu_conv(conv_params(h1, r.cout, nullptr, 0, r.c2_w, r.c2_b, nullptr, 0, skip, out), n, H * W, P(r.gn2_g), P(r.gn2_b), 1e-5f, g2,
-                        gnp_done ? gnp : nullptr);
+        {
+            GemmParams c2 = conv_params(h1, r.cout, nullptr, 0, r.c2_w, r.c2_b, nullptr, 0, skip, out);
+            want_stats(c2, gno, H * W, &gno_done);
+            ex.gn_silu_conv(c2, n, H * W, P(r.gn2_g), P(r.gn2_b), 1e-5f, g2, gnp_done ? gnp : nullptr, gnp_done);
+        }
         ar.release(mk);
-        return {out, r.cout, H, W};
+        return {out, r.cout, H, W, gno_done ? gno : nullptr, gno_done};
     }
 
     // SpatialTransformer.forward (LD.py:4239-4262) around BasicTransformerBlock._forward (LD.py:4117-4162)
-    Feat transformer(const StW& s, const half_t* x, int H, int W) {
+    Feat transformer(const StW& s, const half_t* x, int H, int W, float* in_stats = nullptr, int in_P = 0) {
         Arena& ar = *ex.arena;
         const int C = s.c, L = H * W, heads = u->cfg.num_heads, d = C / heads;
         int M = n * L;                                           // rows the kernels run on (doubles at the split of a CFG pair, below)
         const size_t Ma = (size_t)na() * L;                      // rows the tensors are sized for
         half_t* out = ar.halfs(Ma * C);
+        float* gno = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(na(), L)));   // statistics of `out` (for the next GroupNorm)
+        int gno_done = 0;
         const size_t mk = ar.mark();
         half_t* g = ar.halfs(Ma * C);
-        ex.groupnorm(x, C, nullptr, 0, n, L, P(s.gn_g), P(s.gn_b), 1e-6f, 0, g);
+        ex.groupnorm(x, C, nullptr, 0, n, L, P(s.gn_g), P(s.gn_b), 1e-6f, 0, g, in_stats, in_P);
         half_t* t = ar.halfs(Ma * C);
         const int Lp = (L + 7) & ~7;   // V^T rows are padded to 8 keys (16-byte row copies in the attention kernel)
         half_t* nrm = g;               // reuse (only the un-folded path materialises LN(x))
@@ -504,13 +524,14 @@ struct Run {
             p.bias_n = reinterpret_cast<const half_t*>(fb + s.f_mo_b);
             p.R = x; p.ldr = C;
             p.C = out; p.ldc = C;
+            want_stats(p, gno, L, &gno_done);
             ex.gemm(p);
         } else {
             linear(ff, 4 * C, s.ff2_w, s.ff2_b, t, t, M, C, 4 * C);
             linear(t, C, s.pout_w, s.pout_b, x, out, M, C, C);
         }
         ar.release(mk);
-        return {out, C, H, W};
+        return {out, C, H, W, gno_done ? gno : nullptr, gno_done};
     }
 };
 
@@ -555,6 +576,7 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
     ex.arena = dry ? &plan : &u->arena;
     ex.splitk_ws = u->splitk_ws;
     ex.splitk_bytes = u->splitk_bytes;
+    ex.sync_ws = u->sync_ws;
     if (u->want_timing && !dry) {
         u->timing.reset();
         ex.timing = &u->timing;
@@ -600,12 +622,12 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
         for (const Layer& L : layers) {
             switch (L.kind) {
                 case L_RES: {
-                    f = R.resblock(u->res[L.idx], f.p, f.C, x2, C2, f.H, f.W);
+                    f = R.resblock(u->res[L.idx], f.p, f.C, x2, C2, f.H, f.W, f.gn, f.gnP);
                     x2 = nullptr;
                     C2 = 0;
                     break;
                 }
-                case L_ST: f = R.transformer(u->st[L.idx], f.p, f.H, f.W); break;
+                case L_ST: f = R.transformer(u->st[L.idx], f.p, f.H, f.W, f.gn, f.gnP); break;
                 case L_DOWN: {
                     const ConvW& cw = u->convs[L.idx];
                     const int Ho = (f.H - 1) / 2 + 1, Wo = (f.W - 1) / 2 + 1;
@@ -615,8 +637,10 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
                         R.n = n;
                     }
                     half_t* o = ar.halfs((size_t)n * Ho * Wo * cw.cout);
-                    R.conv3(f.p, f.C, nullptr, 0, f.H, f.W, f.H, f.W, 2, cw.w, cw.b, cw.cout, nullptr, 0, nullptr, o, nullptr, nullptr);
-                    f = {o, cw.cout, Ho, Wo};
+                    float* gno = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(n, Ho * Wo)));
+                    int gno_done = 0;
+                    R.conv3(f.p, f.C, nullptr, 0, f.H, f.W, f.H, f.W, 2, cw.w, cw.b, cw.cout, nullptr, 0, nullptr, o, nullptr, nullptr, 3, gno, &gno_done);
+                    f = {o, cw.cout, Ho, Wo, gno_done ? gno : nullptr, gno_done};
                     break;
                 }
                 case L_UP: {   // Upsample1: nearest resize to the next skip's H x W, then conv (LD.py:5141-5152)
@@ -657,6 +681,8 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
             R.dup(const_cast<half_t*>(f.p), (size_t)R.n * f.H * f.W * f.C * sizeof(half_t));
             R.pair_pending = false;
             R.n = n;
+            f.gn = nullptr;                                      // (its statistics cover the first half of the batch only)
+            f.gnP = 0;
         }
         hs.push_back(f);
     }
@@ -674,7 +700,7 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
     }
     {   // out: GroupNorm + SiLU, 3x3 conv to 4 channels fused with EPS.calculate_denoised, back to fp32 NCHW
         half_t* g = ar.halfs((size_t)n * f.H * f.W * f.C);
-        ex.groupnorm(f.p, f.C, nullptr, 0, n, f.H * f.W, u->pt.ptr(u->outn_g), u->pt.ptr(u->outn_b), 1e-5f, 1, g);
+        ex.groupnorm(f.p, f.C, nullptr, 0, n, f.H * f.W, u->pt.ptr(u->outn_g), u->pt.ptr(u->outn_b), 1e-5f, 1, g, f.gn, f.gnP);
         SmallConvOutArgs a;
         a.x = g; a.w = u->pt.ptr(u->outc_w); a.b = u->pt.ptr(u->outc_b);
         a.N = n; a.H = f.H; a.W = f.W; a.Cin = f.C; a.Cout = c.out_channels;
@@ -724,7 +750,8 @@ int ld_unet_create(const ld_unet_config* cfg, ld_unet** out) {
         delete u;
         return LD_ERR_HIP;
     }
-    if (hipMalloc((void**)&u->log_sigmas, 1000 * sizeof(float)) != hipSuccess ||
+    if (hipMalloc((void**)&u->sync_ws, LD_SYNC_INTS * sizeof(int)) != hipSuccess || hipMemset(u->sync_ws, 0, LD_SYNC_INTS * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&u->log_sigmas, 1000 * sizeof(float)) != hipSuccess ||
         hipMemcpy(u->log_sigmas, ls.data(), 1000 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
         u->pt.destroy();
         delete u;
@@ -740,6 +767,7 @@ void ld_unet_destroy(ld_unet* u) {
     u->timing.destroy();
     if (u->ws_base) (void)hipFree(u->ws_base);
     if (u->log_sigmas) (void)hipFree(u->log_sigmas);
+    if (u->sync_ws) (void)hipFree(u->sync_ws);
     if (u->fold_base) (void)hipFree(u->fold_base);
     delete u;
 }

@@ -1,0 +1,95 @@
+"""GPU parity of the row-resident convolution (csrc/conv8.hip) — the two-image 16x16 / 8x8 levels of a batch-1 step: ResBlock1's
+GroupNorm + SiLU + conv3x3 (+ time-embedding row + skip, LD.py:5224-5287) and Upsample1's nearest-2x + conv (LD.py:5141-5152), called
+through the C ABI (ld_op_groupnorm_conv / ld_op_conv) against a torch fp32 evaluation of the same op on the same fp16-rounded inputs.
+Tolerance: rel-L2 <= 2e-3 (fp16 storage, fp32 accumulate; the channel-slab partial sums are fp32 and summed in a fixed order)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-3
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from lightdiffusion_amd import ops as o
+    from lightdiffusion_amd._lib import lib
+    lib()
+    return o
+
+
+def r16(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).half()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+# (h = w, c1, c2, cout, time-embedding row, residual): every ResBlock convolution of SD1.5's 16x16 / 8x8 levels and the middle block at
+# UNet batch 2 — in_layers of the down path (640 -> 1280, 1280 -> 1280), of the up path (concat 1280 + 1280 / 1280 + 640: groups of 80 / 60
+# channels, the second one straddling the 16-channel sub-slabs AND the source boundary), out_layers (residual = skip)
+@pytest.mark.parametrize("hw,c1,c2,cout,rv,res", [
+    (16, 1280, 0, 1280, True, False), (16, 1280, 0, 1280, False, True), (16, 640, 0, 1280, True, False),
+    (16, 1280, 1280, 1280, True, False), (16, 1280, 640, 1280, True, True),
+    (8, 1280, 0, 1280, True, True), (8, 1280, 1280, 1280, True, False), (8, 1280, 0, 640, False, False)])
+def test_groupnorm_silu_conv_row_resident(ops, hw, c1, c2, cout, rv, res):
+    n, h, w = 2, hw, hw
+    x1 = r16((n, c1, h, w), 201, 2.0) + 0.5
+    x2 = (r16((n, c2, h, w), 202) - 1.0) if c2 else None
+    cin = c1 + c2
+    ga, be = (1 + 0.1 * r16((cin,), 203).float()).half(), r16((cin,), 204, 0.1)
+    wt, b = r16((cout, cin, 3, 3), 205, 1 / math.sqrt(9 * cin)), r16((cout,), 206, 0.1)
+    xin = x1.float().to(DEV) if x2 is None else torch.cat([x1.float(), x2.float()], 1).to(DEV)
+    g = F.silu(F.group_norm(xin, 32, ga.float().to(DEV), be.float().to(DEV), 1e-5))
+    ref = F.conv2d(g, wt.float().to(DEV), b.float().to(DEV), padding=1)
+    rowvec = r16((n, cout), 207) if rv else None
+    if rv:
+        ref = ref + rowvec.float().to(DEV)[:, :, None, None]
+    r = r16(tuple(ref.shape), 208) if res else None
+    if res:
+        ref = ref + r.float().to(DEV)
+    wp = ops.repack_conv_weight(wt.to(DEV))
+    args = (nhwc(x1).to(DEV), ga.to(DEV), be.to(DEV), 1e-5, wp, b.to(DEV), None if x2 is None else nhwc(x2).to(DEV),
+            None if rowvec is None else rowvec.to(DEV), None if r is None else nhwc(r).to(DEV))
+    y = ops.group_norm_silu_conv2d(*args)
+    assert rel_l2(nchw(y.float().cpu()), ref.cpu()) < TOL
+    # the in-launch reduction sums the slabs in a fixed order: replays are bitwise identical, and the counters it leaves behind are zero
+    # (a second call on the same scratch would otherwise hang or reduce early)
+    for _ in range(3):
+        y2 = ops.group_norm_silu_conv2d(*args)
+        assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("hw,cin,cout,up,rv,res", [
+    (16, 1280, 1280, True, False, False),     # Upsample1 of the 8x8 level: nearest 2x inside the halo loader
+    (16, 1280, 1280, False, True, True),      # plain (no GroupNorm) route
+    (8, 1280, 1280, False, False, True)])
+def test_conv_row_resident(ops, hw, cin, cout, up, rv, res):
+    n = 2
+    hs = hw // 2 if up else hw
+    x = r16((n, cin, hs, hs), 211)
+    wt, b = r16((cout, cin, 3, 3), 212, 1 / math.sqrt(9 * cin)), r16((cout,), 213, 0.1)
+    xin = x.float().to(DEV)
+    if up:
+        xin = F.interpolate(xin, size=(hw, hw), mode="nearest")
+    ref = F.conv2d(xin, wt.float().to(DEV), b.float().to(DEV), padding=1)
+    rowvec = r16((n, cout), 214) if rv else None
+    if rv:
+        ref = ref + rowvec.float().to(DEV)[:, :, None, None]
+    r = r16(tuple(ref.shape), 215) if res else None
+    if res:
+        ref = ref + r.float().to(DEV)
+    y = ops.conv2d(nhwc(x).to(DEV), ops.repack_conv_weight(wt.to(DEV)), b.to(DEV), 3, 1, None, (hw, hw) if up else None,
+                   None if rowvec is None else rowvec.to(DEV), None if r is None else nhwc(r).to(DEV))
+    assert rel_l2(nchw(y.float().cpu()), ref.cpu()) < TOL
