@@ -82,13 +82,19 @@ int ld_op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int
     p.C = (half_t*)y; p.ldc = cout;
     p.partial = (float*)ws;
     p.partial_bytes = ws ? ws_bytes : 0;
-    if (ws != nullptr && ws_bytes > ((size_t)8 << 20)) {   // the head of a roomy scratch buffer doubles as the (zeroed) counters of the in-launch reductions
+    if (ws != nullptr && ksize == 3 && conv8_weight_eligible(cout, c1 + c2) && ws_bytes > 1024 + align256(conv8_weight_bytes(cout, c1 + c2)) + ((size_t)8 << 20)) {
+        // row-resident kernel (conv8.hip): the head of a roomy scratch buffer holds the (zeroed) counters of its in-launch reduction and a
+        // copy of the weights in its layout, made per call here (the UNet executor keeps that copy resident)
         GemmParams c8 = p;
+        const size_t w8b = align256(conv8_weight_bytes(cout, c1 + c2));
         c8.sync = (int*)ws;
-        c8.partial = (float*)((char*)ws + 1024);
-        c8.partial_bytes = ws_bytes - 1024;
+        c8.W8 = (const half_t*)((char*)ws + 1024);
+        c8.partial = (float*)((char*)ws + 1024 + w8b);
+        c8.partial_bytes = ws_bytes - 1024 - w8b;
         if (conv8_plan(c8, nullptr)) {
             if (hipMemsetAsync(ws, 0, LD_SYNC_INTS * sizeof(int), (hipStream_t)stream) != hipSuccess) return LD_ERR_HIP;
+            const int st = conv8_repack_launch((const half_t*)wt, cout, c1 + c2, (half_t*)((char*)ws + 1024), (hipStream_t)stream);
+            if (st != LD_OK) return st;
             return gemm_launch(c8, (hipStream_t)stream);
         }
     }
@@ -98,7 +104,7 @@ int ld_op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int
 size_t ld_op_groupnorm_conv_ws_bytes(int c1, int c2, int n, int h, int w, int cout) {
     const size_t C = (size_t)c1 + c2, HW = (size_t)h * w;
     return align256(groupnorm_workspace_bytes(n, (int)HW)) + 2 * align256((size_t)n * C * sizeof(float)) + align256((size_t)n * HW * C * sizeof(half_t)) +
-           align256(LD_SYNC_INTS * sizeof(int)) + ((size_t)96 << 20);
+           align256(LD_SYNC_INTS * sizeof(int)) + (conv8_weight_eligible(cout, c1 + c2) ? align256(conv8_weight_bytes(cout, c1 + c2)) : 0) + ((size_t)96 << 20);
 }
 
 int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int w, const void* gamma, const void* beta, float eps,
@@ -116,6 +122,11 @@ int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, 
     float* shift = (float*)q; q += align256((size_t)n * C * sizeof(float));
     half_t* g = (half_t*)q; q += align256((size_t)n * HW * C * sizeof(half_t));
     int* sync = (int*)q; q += align256(LD_SYNC_INTS * sizeof(int));
+    half_t* w8 = nullptr;
+    if (conv8_weight_eligible(cout, C)) {
+        w8 = (half_t*)q;
+        q += align256(conv8_weight_bytes(cout, C));
+    }
     GemmParams p;
     p.conv = 1; p.ksize = 3;
     p.A = (const half_t*)x1; p.A2 = (const half_t*)x2; p.C1 = c1; p.C2 = c2;
@@ -130,11 +141,20 @@ int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, 
     {   // row-resident kernel (conv8.hip): statistics pass, then the convolution finishes and applies the normalisation itself
         GemmParams c8 = p;
         c8.sync = sync;
+        c8.W8 = w8;
         c8.gn_in_part = part; c8.gn_in_P = gn_num_chunks(n, HW);
         c8.gn_gamma = (const half_t*)gamma; c8.gn_beta = (const half_t*)beta; c8.gn_eps = eps; c8.gn_silu = 1;
-        if (conv8_plan(c8, nullptr)) {
+        bool direct = conv8_plan(c8, nullptr), tables = false;
+        if (!direct) {
+            c8.gn_scale = scale; c8.gn_shift = shift;
+            tables = conv8_plan(c8, nullptr);
+        }
+        if (direct || tables) {
             if (hipMemsetAsync(sync, 0, LD_SYNC_INTS * sizeof(int), stream) != hipSuccess) return LD_ERR_HIP;   // (a caller's scratch: not known to be zero)
-            int st = groupnorm_stats_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, HW, part, stream);
+            int st = tables ? groupnorm_scale_shift_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, HW, (const half_t*)gamma, (const half_t*)beta, eps, part, scale, shift, stream)
+                            : groupnorm_stats_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, HW, part, stream);
+            if (tables) c8.gn_in_part = nullptr;
+            if (st == LD_OK) st = conv8_repack_launch((const half_t*)wt, cout, C, w8, stream);   // (per call here; the UNet executor keeps the copy resident)
             if (st != LD_OK) return st;
             return gemm_launch(c8, stream);
         }

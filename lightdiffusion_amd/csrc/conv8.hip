@@ -1,105 +1,137 @@
-// conv8: row-resident 3x3 convolution for the small-M levels of a batch-1 step (UNet batch 2: the 16x16 and 8x8 levels and the
-// middle block — ResBlock1 convolutions, LD.py:5189-5287, and Upsample1's convolution, LD.py:5141-5152).
+// conv8: row-resident 3x3 convolution (stride 1, pad 1, optional nearest-2x upsampling of the input) for launches whose M is too small
+// to fill the chip with the big-tile kernels — every ResBlock1 convolution (LD.py:5189-5287) and Upsample1 convolution (LD.py:5141-5152)
+// of a batch-1 step (UNet batch 2) on all four levels, and the 8x8 level up to UNet batch 16.
 //
-// Why a separate kernel: at M = 128 / 512 rows the 64 x 160 tiles of the general kernel re-read every weight byte once per M tile and
-// every activation byte nine times, ~10x the unique bytes of the launch, through a per-CU LDS-DMA path that takes in ~30 GB/s from beyond
-// L2 (profiles/README.md round 4) — 35..40 us for 29.5 MB of weights.  Here
-//   * one workgroup owns ALL M rows x 80 output channels x a slab of the input channels (all nine taps): every weight byte enters exactly
-//     one CU, once (LDS-DMA ring, three 25 KB stages in flight), and the grid is (N / 80) x S = 256 workgroups, one per CU;
-//   * the activations of a 16-channel sub-slab sit in LDS as a zero-bordered halo image (IMGS x (W+2)^2 pixels x 32 bytes), staged
-//     through registers by waves 4-7 — which is where the GroupNorm + SiLU of the input is applied (scale / shift finished in the
-//     prologue from the producer's partial statistics): no gn_apply launch, no normalised tensor in HBM; waves 0-3 issue the weight DMA;
+// Why a separate kernel: at M = 128 .. 8192 rows the 64 x 160 tiles of the general kernel + a split over K + a reduce launch + the
+// GroupNorm launches in front run at 10-20 % of either roof (profiles/README.md round 4): every weight byte is re-read once per M tile and
+// every activation byte nine times through a per-CU LDS-DMA path that takes in ~30 GB/s from beyond L2.  Here
+//   * a workgroup owns a 128-pixel patch (whole image rows; two whole images at 8x8) x 80 output channels x a slab of the input
+//     channels, all nine taps.  Grid = patches x (N / 80) x S = ~256 workgroups, one per CU.  The patches that share a weight slab are
+//     placed on ONE XCD (speed only: blockIdx -> XCD is a label), so a weight byte leaves HBM once and reaches the other patches' CUs
+//     through that XCD's L2;
+//   * the weights are read from a copy in the kernel's OWN layout (conv8_repack_launch: [N / 80][Cin / 16][the 25 600-byte LDS image of one
+//     ring stage, swizzle and the zero tenth tap included]): a workgroup's whole stream is ONE contiguous byte range and every LDS-DMA
+//     instruction copies 1 KB of consecutive bytes (streaming the general [O][tap][I] layout in 32-byte runs measured 6 GB/s per CU:
+//     every run pulls its whole 128-byte line from HBM, and the line is evicted before the next sub-slab asks for it);
+//   * the activations sit in LDS as a zero-bordered halo image per 16-channel plane, staged through registers by waves 4-7 in groups of
+//     two planes (64 contiguous bytes per pixel), double buffered — which is where the GroupNorm + SiLU of the input is applied (scale /
+//     shift finished in the prologue from partial statistics): no gn_apply launch, no normalised tensor in HBM; waves 0-3 issue the
+//     weight DMA (a four-stage ring, three stages in flight);
 //   * a k-step of the 16x16x32 MFMA = two taps x 16 channels (the tenth "tap" is a zero weight chunk), so a lane's tap offset is one of
 //     five precomputed values and every fragment read is base + immediate;
-//   * the S channel-slab partial sums of an N tile meet in HBM (fp32, written through with sc1 stores) and are reduced INSIDE the launch:
-//     arrive counter -> (bounded wait) -> the row parts of the tile are claimed one by one, summed in slab order (bitwise reproducible),
-//     finished with bias / time-embedding row / residual, stored as fp16 — and the GroupNorm partial statistics of the OUTPUT are
-//     emitted per (image, row part, group), so the next GroupNorm needs no statistics launch either.  A workgroup that cannot wait
-//     (time-out: its peers are not resident) leaves; the last arriver always finds every slab complete and takes whatever is left, so
-//     the protocol terminates and is correct under any dispatch order or placement (cdna guide, Guideline 16: sc1 payload stores, every
-//     storing wave drains vmcnt, one lane signals; the readers acquire once and load with sc1).
-// One launch replaces gn_apply + conv + split-K reduce (+ gn_stats of the next norm).
+//   * the S channel-slab partial sums of a (patch, N tile) meet in HBM (fp32, written through with sc1 stores) and are reduced INSIDE the
+//     launch: arrive counter -> (bounded wait) -> the eight 16-row parts of the tile are claimed one by one, summed in slab order (bitwise
+//     reproducible), finished with bias / time-embedding row / residual, stored as fp16 — and the GroupNorm partial statistics of the
+//     OUTPUT are emitted per (image, 16-pixel chunk, group), so the next GroupNorm needs no statistics launch either.  A workgroup that
+//     cannot wait (time-out: its peers are not resident) leaves; the last arriver always finds every slab complete and takes whatever is
+//     left, so the protocol terminates and is correct under any dispatch order or placement (cdna guide, Guideline 16: sc1 payload stores,
+//     every storing wave drains vmcnt, one lane signals; the readers acquire once and load with sc1).
+// One launch replaces gn_apply + conv + split-K reduce (+ gn_stats of the next norm).  Small patches keep S small: the fp32 slabs
+// (S x M x N x 4 bytes, written and read once) were the largest cost of a first version with 512-row tiles (S = 16: 84 MB per launch).
+#include <cstdlib>
+#include <type_traits>
+
 #include "gemm.h"
 
 namespace {
 
 constexpr int C8_BN = 80;                 // output channels per workgroup
-constexpr int C8_THREADS = 512;
+constexpr int C8_THREADS = 768;            // 12 waves: 0-3 MFMA consumers, 4-7 halo staging, 8-11 weight DMA
 constexpr int C8_RING = 4;                // weight ring stages (one 16-channel sub-slab each)
 constexpr int C8_WSTAGE = 5 * C8_BN * 64; // 5 k-steps x 80 rows x 64 B = 25 wave-instructions of 1 KB
-constexpr int C8_MAXCW = 160;             // channels of one workgroup's slab (scale / shift table)
+constexpr int C8_MAXCW = 960;             // channels of one workgroup's slab (scale / shift table)
+constexpr int C8_PFD = 8;                 // L2 warm-up distance of the weight stream, in stages ahead of the DMA
+constexpr int C8_MAXPAIR = 24;            // (image, group) pairs one slab can touch
 
-__device__ uint4 g_c8_zero[8];            // 128 zero bytes: the tenth "tap" of a k-step pair
+__device__ uint4 g_c8_zero[1024];          // 16 KB of zeros: stands in for an absent bias / row vector / residual (row stride 0)
 
 __device__ __forceinline__ int c8_g(int x) { return (0x78 >> (2 * (x & 3))) & 3; }   // {0, 2, 3, 1}: 64-byte-row swizzle of the weight stage (gemm5's)
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void st16_sc1(float* p, f32x4 v) {   // write-through 16-byte store (agent scope)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
+__device__ __forceinline__ void glds16b(unsigned voff, const char* sbase, unsigned lds_base) {   // LDS-DMA, scalar base + per-lane byte offset
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(sbase), "s"(lds_base)
+        : "memory");
+}
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ f32x4 ld16_sc1(const float* p) {      // L1-bypassing 16-byte load, result usable after the caller's vmcnt wait
     f32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
 
-template <int WD, int IMGS, bool GN, bool UP>
-__global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(const GemmParams p) {
-    constexpr int HP = WD + 2, HPP = HP * HP, HPIX = IMGS * HPP;
-    constexpr int MT = IMGS * WD * WD, RT = MT / 16, TM = RT / 8;
-    constexpr int HALO_B = HPIX * 32;
-    constexpr int NCH = (HPIX * 2 + 255) / 256;            // halo chunks per thread of the four staging waves
-    constexpr int NP = MT >= 512 ? 16 : 8;                  // row parts of a tile (claimed one by one in the reduction)
-    constexpr int RTPP = RT / NP;                           // 16-row tiles per part
-    constexpr int ITEMS = RTPP * 5 * 64;                    // float4 items per part
-    static_assert(RT % 8 == 0 && RT % NP == 0, "tile shape");
+// WD: image width (= height).  A patch = 128 output pixels: two whole images (WD = 8) or 128 / WD whole rows of one image.
+template <int WD, bool GN, bool UP>
+__global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p) {
+    constexpr int TI = WD == 8 ? 2 : 1;                      // images per patch
+    constexpr int RH = WD == 8 ? 8 : 128 / WD;               // image rows per patch (per image)
+    constexpr int HP = WD + 2, HR = RH + 2, HPI = HR * HP, HPIX = TI * HPI;   // halo: pixels per row, rows, per image, total
+    constexpr int PLANE_B = HPIX * 32;                       // one 16-channel plane of the halo image
+    constexpr int GROUP_B = 2 * PLANE_B;                     // staged two planes (32 channels = 64 contiguous source bytes per pixel) at a time
+    constexpr int NCH = (HPIX * 4 + 255) / 256;              // halo chunks per thread of the four staging waves and group
+    constexpr int ITEMS = 5 * 64;                            // float4 items of one 16-row part
     extern __shared__ __attribute__((aligned(16))) char smem8[];
     char* const wring = smem8;
     char* const halo = smem8 + C8_RING * C8_WSTAGE;
-    float* const gsc = reinterpret_cast<float*>(halo + 2 * HALO_B);   // [IMGS][160] scale, then [IMGS][160] shift
-    float* const gsh = gsc + IMGS * C8_MAXCW;
-    float* const gmr = gsh + IMGS * C8_MAXCW;                           // [IMGS][16][2] mean / rstd of the slab's groups
-    int* const flags = reinterpret_cast<int*>(gmr + IMGS * 32);
+    float* const gsc = reinterpret_cast<float*>(halo + 2 * GROUP_B);   // [TI][MAXCW] scale, then [TI][MAXCW] shift
+    float* const gsh = gsc + TI * C8_MAXCW;
+    float* const gred = gsh + TI * C8_MAXCW;                            // [4 waves][MAXPAIR][2] partial (sum, sum of squares) of the slab's groups
+    int* const flags = reinterpret_cast<int*>(gred + 4 * C8_MAXPAIR * 2);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
-    const int NTN = p.N / C8_BN, S = p.c8_S;
-    const int j = blockIdx.x % NTN, s = blockIdx.x / NTN;
+    const int NTN = p.N / C8_BN, S = p.c8_S, TMS = p.M / 128;
+#ifdef LD_AB_BUILD
+    // phase clocks (tools/conv8_phases.py): waves 0 and 4 of every workgroup stamp s_memrealtime (100 MHz) at the phase boundaries
+    unsigned long long* const stamps = p.dbg ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.partial) + p.partial_bytes - 65536) + blockIdx.x * 16 + (tid >= 256 ? 8 : 0) : nullptr;   // (wave 0 / wave 4)
+#define C8_STAMP(i) do { if (stamps != nullptr && (tid == 0 || tid == 256)) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define C8_STAMP(i) do { } while (0)
+#endif
+    C8_STAMP(0);
+    // block -> (weight slab q = (s, j), patch tm): logical id q * TMS + tm, and every XCD takes a contiguous run of logical ids (blocks b and
+    // b + 8 share an XCD under round-robin placement): the patches of one slab sit on ONE XCD and stream its weights through that L2 together
+    const int lid = xcd_remap(blockIdx.x, NTN * S * TMS);
+    const int q = lid / TMS, tm = lid - q * TMS;
+    const int j = q % NTN, s = q / NTN;
+#ifdef LD_AB_BUILD
+    if (stamps != nullptr && tid == 0) {   // which XCD runs this (slab, patch): hardware id, read for the placement check of tools/conv8_phases.py
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stamps[6] = xcc & 15u;
+        stamps[7] = ((unsigned long long)q << 32) | (unsigned)tm;
+    }
+#endif
     const int Cin = p.C1 + p.C2;
     const int nsub = Cin >> 4;
     const int sb = (int)((long long)s * nsub / S), se = (int)((long long)(s + 1) * nsub / S);
     const int nloc = se - sb;
+    const int HW = WD * WD;
+    const int img0 = WD == 8 ? tm * 2 : tm / (WD / RH), y0 = WD == 8 ? 0 : (tm % (WD / RH)) * RH;   // first image / first image row of the patch
 
-    // ------------------------------------------------------------------------------------------ loader state (waves 0-3)
-    const half_t* wsrc[7];
-    unsigned wvalid = 0;
+    // ------------------------------------------------------------------------------------------ weight stream (waves 8-11)
+    // this workgroup's stages are consecutive 25 600-byte blocks of the repacked weights: piece i of a stage = bytes [1024 i, 1024 i + 1024)
+    const char* wbase = reinterpret_cast<const char*>(p.W8) + ((long long)j * nsub + sb) * C8_WSTAGE;   // wave-uniform, advances one stage per issue
     const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)wring);
-    if (wid < 4) {
+    const int wd = wid - 8;              // DMA wave 0..3 takes pieces wd, wd + 4, ...: 7 (wd = 0) or 6 one-KB pieces of a stage
+    const unsigned wlane = (unsigned)(wd * 1024 + lane * 16);
+    auto w_issue = [&](int slot) {
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
-            const int q = wid + 4 * u;
-            const int c = 64 * (q < 25 ? q : 24) + lane;
-            const int t = c / 320, rem = c - 320 * t;
-            const int n = rem >> 2, pc = rem & 3;
-            const int fql = pc ^ c8_g(n >> 2);
-            const int tap = 2 * t + (fql >> 1), cc = fql & 1;
-            const bool ok = tap < 9;
-            wsrc[u] = ok ? p.W + (long long)(j * C8_BN + n) * p.ldw + (long long)tap * Cin + sb * 16 + cc * 8 : reinterpret_cast<const half_t*>(g_c8_zero);
-            wvalid |= ok ? (1u << u) : 0u;
+            if (u == 6 && wd != 0) break;
+            glds16b(wlane + (unsigned)(u * 4096), wbase, ring_base + (unsigned)(slot * C8_WSTAGE + (wd + 4 * u) * 1024));
         }
-    }
-    auto w_issue = [&](int slot) {       // one 16-channel sub-slab of the weights: 25 one-KB pieces, wave w takes pieces w, w+4, ...
-#pragma unroll
-        for (int u = 0; u < 7; ++u) {
-            if (u == 6 && wid != 0) break;
-            glds16(wsrc[u], ring_base + (unsigned)(slot * C8_WSTAGE + (wid + 4 * u) * 1024));
-            wsrc[u] += (wvalid >> u) & 1 ? 16 : 0;
-        }
+        wbase += C8_WSTAGE;
     };
     auto w_wait = [&](int ahead) {       // this wave's pieces of a stage have landed: all but the pieces of the `ahead` stages issued after it
-        if (wid == 0) {
+        if (wd == 0) {
             if (ahead >= 2) wait_vmcnt<14>();
             else if (ahead == 1) wait_vmcnt<7>();
             else wait_vmcnt<0>();
@@ -110,178 +142,368 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(const GemmParams p
         }
     };
 
-    // ------------------------------------------------------------------------------------------ halo staging state (waves 4-7)
+    // ------------------------------------------------------------------------------------------ halo staging (waves 4-7)
+    const bool halo_wave = wid >= 4 && wid < 8;
+    // chunk c of a group: pixel c >> 2, plane (c >> 1) & 1, half-plane c & 1 — four consecutive lanes read one pixel's 64 contiguous bytes
     const int t4 = tid - 256;
-    int hpl[NCH];          // source pixel (linear index into the NHWC source, in pixels), -1 = border / beyond the image
-    int himg[NCH];
-    uint4 hreg[NCH];
-    if (wid >= 4) {
+    int hsp[NCH], himg[NCH];       // source pixel (linear, NHWC, in pixels; -1 = zero border) and patch-local image of this thread's chunks
+    uint4 hregA[NCH], hregB[NCH];  // group h travels in set h & 1: loaded one whole group before it is normalised and stored (the L2 latency of
+                                   // a load-then-store staging was the pole of the loop: 2.2 us per group against 0.9 us of MFMA)
+    if (halo_wave) {
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
-            const int c = t4 + 256 * u;
-            const int pix = c >> 1;
-            const int img = pix / HPP, r2 = pix - img * HPP;
+            const int pix = (t4 + 256 * u) >> 2;
+            const int il = pix / HPI, r2 = pix - il * HPI;
             const int hy = r2 / HP, hx = r2 - hy * HP;
-            const bool in = c < HPIX * 2 && hy >= 1 && hy <= WD && hx >= 1 && hx <= WD;
-            const int sy = UP ? (hy - 1) >> 1 : hy - 1, sx = UP ? (hx - 1) >> 1 : hx - 1;
-            himg[u] = img;
-            hpl[u] = in ? (img * p.Hs + sy) * p.Ws + sx : -1;
+            const int iy = y0 - 1 + hy, ix = hx - 1;                                  // position in the (upsampled) image the convolution sees
+            const bool in = pix < HPIX && iy >= 0 && iy < WD && ix >= 0 && ix < WD;
+            const int sy = UP ? iy >> 1 : iy, sx = UP ? ix >> 1 : ix;
+            himg[u] = il;
+            hsp[u] = in ? ((img0 + il) * p.Hs + sy) * p.Ws + sx : -1;
         }
     }
-    auto halo_load = [&](int ss) {
-        const int c0 = ss * 16;
-        const bool second = c0 >= p.C1;
-        const half_t* src = second ? p.A2 : p.A;
-        const int Cs = second ? p.C2 : p.C1, cl = second ? c0 - p.C1 : c0;
-#pragma unroll
-        for (int u = 0; u < NCH; ++u) {
-            const int cc = (t4 + 256 * u) & 1;
-            hreg[u] = hpl[u] >= 0 ? ld16(src + (long long)hpl[u] * Cs + cl + cc * 8) : zero16();
-        }
-    };
-    auto halo_store = [&](int k, int buf) {   // k: sub-slab index inside this workgroup's slab (scale / shift table offset)
+    auto halo_load = [&](int g, uint4 (&hreg)[NCH]) {   // group g = sub-slabs sb + 2g, sb + 2g + 1 (the second one may lie beyond the slab: loaded, never read)
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
             const int c = t4 + 256 * u;
-            if (c >= HPIX * 2) continue;
-            uint4 v = hreg[u];
-            if (GN && hpl[u] >= 0) {
-                const int cc = c & 1;
-                const float* sc = gsc + himg[u] * C8_MAXCW + k * 16 + cc * 8;
-                const float* sh = gsh + himg[u] * C8_MAXCW + k * 16 + cc * 8;
+            int ss = sb + 2 * g + ((c >> 1) & 1);
+            ss = ss < nsub ? ss : nsub - 1;
+            const int c0 = ss * 16;
+            const bool second = c0 >= p.C1;
+            const half_t* src = second ? p.A2 : p.A;
+            const int Cs = second ? p.C2 : p.C1, cl = second ? c0 - p.C1 : c0;
+            // (always a load — a select between a load and zeros makes hipcc branch around every load and wait for each one: the border
+            // pixels read source pixel 0 and are zeroed when they are stored)
+            hreg[u] = ld16(src + (long long)(hsp[u] >= 0 ? hsp[u] : 0) * Cs + cl + (c & 1) * 8);
+        }
+    };
+    auto halo_store = [&](int g, int buf, const uint4 (&hreg)[NCH]) {
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int c = t4 + 256 * u;
+            if (c >= HPIX * 4) continue;
+            const int pix = c >> 2, pl = (c >> 1) & 1, cc = c & 1;
+            uint4 v = hsp[u] >= 0 ? hreg[u] : zero16();
+            if (GN && hsp[u] >= 0) {
+                const int k = 2 * g + pl;                        // sub-slab inside this workgroup's slab
+                const int kk = k < nloc ? k : nloc - 1;
+                const float* sc = gsc + himg[u] * C8_MAXCW + kk * 16 + cc * 8;
+                const float* sh = gsh + himg[u] * C8_MAXCW + kk * 16 + cc * 8;
                 float f[8];
                 unpack8(v, f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     f[e] = f[e] * sc[e] + sh[e];
-                    if (p.gn_silu) f[e] = silu_f(f[e]);
+                    if (p.gn_silu) f[e] = silu_fast(f[e]);
                 }
                 v = pack8(f);
             }
-            *reinterpret_cast<uint4*>(halo + buf * HALO_B + c * 16) = v;
+            *reinterpret_cast<uint4*>(halo + buf * GROUP_B + pl * PLANE_B + pix * 32 + cc * 16) = v;
+        }
+    };
+
+    // L2 warm-up of the weight stream (halo waves): where several patches share a slab (TMS > 1) about a quarter of every stage's lines
+    // miss L2 in the workgroup that asks first, and because a wave's LDS-DMA completes in order every stage then lands with the HBM latency
+    // (measured: 25 GB/s per CU with three stages in flight although 70 % of the requests hit).  One dword per 128-byte line, C8_PFD stages
+    // ahead of the DMA, never consumed: by the time the DMA asks, the line is in the XCD's L2 for all patches.
+    const char* const wslab = reinterpret_cast<const char*>(p.W8) + ((long long)j * nsub + sb) * C8_WSTAGE;
+    auto w_prefetch = [&](int st0, int nst) {      // stages [st0, st0 + nst) of this workgroup's slab, clipped
+        if (TMS <= 1) return;
+        const int l0 = st0 * (C8_WSTAGE / 128), l1 = (st0 + nst < nloc ? st0 + nst : nloc) * (C8_WSTAGE / 128);
+        for (int l = l0 + t4; l < l1; l += 256) {
+            unsigned dummy;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(dummy) : "v"(wslab + (long long)l * 128) : "memory");
         }
     };
 
     // ------------------------------------------------------------------------------------------ prologue
-    if (wid < 4) {
+    const int cpg_i = Cin / 32;
+    half_t gam[2] = {(half_t)0.f, (half_t)0.f}, bet[2] = {(half_t)0.f, (half_t)0.f};
+    const int g0 = GN ? (sb * 16) / cpg_i : 0, ng = GN ? (se * 16 - 1) / cpg_i - g0 + 1 : 0;   // groups this slab touches
+    if (wid >= 8) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < C8_RING - 1; ++k)
             if (k < nloc) w_issue(k);
-    } else {
-        halo_load(sb);
-        if (GN) {   // mean / rstd of the groups this slab touches, from the producer's partial statistics (fixed summation order)
-            const int cpg = Cin / 32;
-            const int g0 = (sb * 16) / cpg, g1 = (se * 16 - 1) / cpg, ng = g1 - g0 + 1;
-            if (t4 < IMGS * ng) {
-                const int img = t4 / ng, g = g0 + t4 - img * ng;
-                const float* pp = p.gn_in_part + ((long long)img * p.gn_in_P * 32 + g) * 2;
-                float a = 0.f, b = 0.f;
-                for (int i = 0; i < p.gn_in_P; ++i) {
-                    a += pp[(long long)i * 64];
-                    b += pp[(long long)i * 64 + 1];
+    } else if (halo_wave) {
+        halo_load(0, hregA);
+        if (2 < nloc) halo_load(1, hregB);
+        w_prefetch(C8_RING - 1, C8_PFD);
+        if (GN && p.gn_scale == nullptr) {   // gamma / beta of this thread's first two table entries go out now, under the statistics loads
+            const int cw = nloc * 16;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = t4 + 256 * u, ee = e < TI * cw ? e : 0;
+                const int cg = sb * 16 + ee % cw;
+                gam[u] = p.gn_gamma[cg];
+                bet[u] = p.gn_beta[cg];
+            }
+        }
+        if (GN) {   // (sum, sum of squares) of the slab's groups from the producer's partial statistics [n][P][32][2]: every load goes out before the
+                    // first add; thread t sums chunks t, t + 256, ...; fixed xor tree per wave, the four wave partials are added in wave order below
+            const int npair = TI * ng;
+            if (p.gn_scale == nullptr) {
+                // thread t owns chunk t of the partials (P <= 256: gn_num_chunks and conv8_gn_chunks never exceed it; conv8_plan checks)
+                const int i0 = t4 < p.gn_in_P ? t4 : 0;
+                float2 x[C8_MAXPAIR];
+#pragma unroll
+                for (int pr = 0; pr < C8_MAXPAIR; ++pr) {          // (no branch around a load: pairs beyond npair re-read the last one)
+                    const int pp = pr < npair ? pr : npair - 1;
+                    const int il = pp / ng, g = g0 + pp - il * ng;
+                    x[pr] = *reinterpret_cast<const float2*>(p.gn_in_part + (((long long)(img0 + il) * p.gn_in_P + i0) * 32 + g) * 2);
                 }
-                const float cnt = (float)cpg * (float)(p.Hs * p.Ws);
-                const float mu = a / cnt;
-                const float var = fmaxf(b / cnt - mu * mu, 0.f);
-                gmr[(img * 16 + (g - g0)) * 2] = mu;
-                gmr[(img * 16 + (g - g0)) * 2 + 1] = rsqrtf(var + p.gn_eps);
+                // wave sums, four pairs (eight values) per pass so that the shuffles of a butterfly step go out back to back (one pair after
+                // the other is 12 dependent ds_bpermute round trips per pair: 4 us of the prologue, measured)
+                const bool mine = t4 < p.gn_in_P;
+#pragma unroll
+                for (int c = 0; c < C8_MAXPAIR / 4; ++c) {
+                    if (4 * c < npair) {
+                        float a[4], b[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            a[u] = mine ? x[4 * c + u].x : 0.f;
+                            b[u] = mine ? x[4 * c + u].y : 0.f;
+                        }
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                a[u] += __shfl_xor(a[u], o, 64);
+                                b[u] += __shfl_xor(b[u], o, 64);
+                            }
+                        }
+                        if (lane == 0) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                gred[((wid - 4) * C8_MAXPAIR + 4 * c + u) * 2] = a[u];
+                                gred[((wid - 4) * C8_MAXPAIR + 4 * c + u) * 2 + 1] = b[u];
+                            }
+                        }
+                    }
+                }
             }
         }
     }
     if (GN) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS writes above
         __builtin_amdgcn_s_barrier();
-        if (wid >= 4) {
-            const int cpg = Cin / 32;
-            const int g0 = (sb * 16) / cpg;
+        if (halo_wave) {
             const int cw = nloc * 16;
-            for (int e = t4; e < IMGS * cw; e += 256) {
-                const int img = e / cw, c = e - img * cw;
-                const int cg = sb * 16 + c, g = cg / cpg - g0;
-                const float mu = gmr[(img * 16 + g) * 2], rs = gmr[(img * 16 + g) * 2 + 1];
-                const float sc = rs * (float)p.gn_gamma[cg];
-                gsc[img * C8_MAXCW + c] = sc;
-                gsh[img * C8_MAXCW + c] = (float)p.gn_beta[cg] - mu * sc;
+            const float cnt = (float)cpg_i * (float)(p.Hs * p.Ws);
+            int it = 0;
+            for (int e = t4; e < TI * cw; e += 256, ++it) {
+                const int il = e / cw, c = e - il * cw;
+                const int cg = sb * 16 + c;
+                if (p.gn_scale != nullptr) {                      // finished by the caller (a slab that touches many groups: gn_finalize_kernel)
+                    gsc[il * C8_MAXCW + c] = p.gn_scale[(long long)(img0 + il) * Cin + cg];
+                    gsh[il * C8_MAXCW + c] = p.gn_shift[(long long)(img0 + il) * Cin + cg];
+                    continue;
+                }
+                const int pr = il * ng + cg / cpg_i - g0;
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    a += gred[(w * C8_MAXPAIR + pr) * 2];
+                    b += gred[(w * C8_MAXPAIR + pr) * 2 + 1];
+                }
+                const float mu = a / cnt;
+                const float rs = rsqrtf(fmaxf(b / cnt - mu * mu, 0.f) + p.gn_eps);
+                const float ga = it == 0 ? (float)gam[0] : it == 1 ? (float)gam[1] : (float)p.gn_gamma[cg];
+                const float be = it == 0 ? (float)bet[0] : it == 1 ? (float)bet[1] : (float)p.gn_beta[cg];
+                const float sc = rs * ga;
+                gsc[il * C8_MAXCW + c] = sc;
+                gsh[il * C8_MAXCW + c] = be - mu * sc;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    if (wid >= 4) halo_store(0, 0);
+    if (halo_wave) halo_store(0, 0, hregA);
+    C8_STAMP(1);
 
-    // ------------------------------------------------------------------------------------------ fragment addressing
-    const int rt0 = wid * TM;
-    int pix0;
-    if (WD == 16) {
-        const int img = rt0 >> 4, y = rt0 & 15;                 // a 16-row tile = one image row
-        pix0 = img * HPP + y * HP + fr;
-    } else {
-        const int img = rt0 >> 2, y0 = (rt0 & 3) * 2;           // W = 8: a 16-row tile = two image rows
-        pix0 = img * HPP + (y0 + (fr >> 3)) * HP + (fr & 7);
-    }
-    const int a_lane = pix0 * 32 + (fq & 1) * 16;
-    int toff[5];
+    // ------------------------------------------------------------------------------------------ main loop: one 16-channel sub-slab per barrier
+    // Three roles with SEPARATE code paths (one s_barrier per sub-slab joins them): waves 0-3 = consumers — fragment reads and MFMA only
+    // (wave w owns rows 32 w .. 32 w + 31 of the patch: two 16-row tiles x five 16-column tiles); waves 4-7 = the halo staging with its
+    // global loads; waves 8-11 = the weight DMA with its counted waits.  Measured on the way here (profiles/README.md round 4): with shared
+    // code hipcc parks a vmcnt(0) for the halo registers in front of every fragment read, which drains the weight ring each sub-slab
+    // (3.5x slower); with the DMA issued by the consumers its 6-7 issues per sub-slab (60-180 cycles each) sit in front of the same wave's
+    // 50 MFMAs (1.15 us per sub-slab instead of ~0.5).
+    f32x4 acc[2][5];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        int tap = 2 * t + (fq >> 1);
-        tap = tap > 8 ? 8 : tap;                                // (the tenth tap's weights are zero: any finite activation will do)
-        toff[t] = ((tap / 3) * HP + (tap % 3)) * 32;
-    }
-    const int b_lane = fr * 64 + ((fq ^ c8_g(fr >> 2)) << 4);
-
-    f32x4 acc[TM][5];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jj = 0; jj < 5; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ------------------------------------------------------------------------------------------ main loop: one 16-channel sub-slab per barrier
-    for (int k = 0; k < nloc; ++k) {
-        if (wid < 4) w_wait(nloc - 1 - k);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's halo writes of sub-slab k
-        __builtin_amdgcn_s_barrier();
-        if (wid < 4) {
-            if (k + 3 < nloc) w_issue((k + 3) & 3);
-        } else if (k + 1 < nloc) {
-            halo_load(sb + k + 1);
+    if (wid >= 8) {           // ---- weight DMA: stage k + 3 goes out as soon as everybody is past stage k - 1 (three stages in flight)
+        for (int k = 0; k < nloc; ++k) {
+            w_wait(nloc - 1 - k);
+            __builtin_amdgcn_s_barrier();
+            if (k + C8_RING - 1 < nloc) w_issue((k + C8_RING - 1) & (C8_RING - 1));   // into the stage that was read in iteration k - 1
         }
-        const char* wst = wring + (k & 3) * C8_WSTAGE + b_lane;
-        const char* hb = halo + (k & 1) * HALO_B + a_lane;
+    } else if (wid >= 4) {    // ---- halo staging
+        for (int k = 0; k < nloc; ++k) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's halo writes of the group that starts here
+            __builtin_amdgcn_s_barrier();
+            const int g = k >> 1;
+            // at the start of group g: group g + 1 (loaded a group ago) goes into the other buffer — its previous contents were read before the
+            // barrier that opened this group — and the loads of group g + 2 go out into the register set that just became free
+            if (!(k & 1) && 2 * g + 2 < nloc) {
+                if (g & 1) {
+                    halo_store(g + 1, 0, hregA);
+                    if (2 * g + 4 < nloc) halo_load(g + 2, hregB);
+                } else {
+                    halo_store(g + 1, 1, hregB);
+                    if (2 * g + 4 < nloc) halo_load(g + 2, hregA);
+                }
+            }
+            if (!(k & 1)) w_prefetch(k + C8_RING - 1 + C8_PFD, 2);
+        }
+    } else {
+        int pixa[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rt = wid * 2 + i;
+            if (WD == 8) pixa[i] = (rt >> 2) * HPI + ((rt & 3) * 2 + (fr >> 3)) * HP + (fr & 7);
+            else if (WD == 16) pixa[i] = rt * HP + fr;
+            else if (WD == 32) pixa[i] = (rt >> 1) * HP + (rt & 1) * 16 + fr;
+            else pixa[i] = (rt >> 2) * HP + (rt & 3) * 16 + fr;
+        }
+        const int a_lane0 = pixa[0] * 32 + (fq & 1) * 16, a_lane1 = pixa[1] * 32 + (fq & 1) * 16;
+        int toff[5];
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
-            half8 fa[TM], fb[5];
-#pragma unroll
-            for (int jj = 0; jj < 5; ++jj) fb[jj] = as_half8(*reinterpret_cast<const uint4*>(wst + t * 5120 + jj * 1024));
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = as_half8(*reinterpret_cast<const uint4*>(hb + toff[t] + i * (HP * 32)));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 5; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[jj], fa[i], acc[i][jj], 0, 0, 0);
+            int tap = 2 * t + (fq >> 1);
+            tap = tap > 8 ? 8 : tap;                            // (the tenth tap's weights are zero: any finite activation will do)
+            toff[t] = ((tap / 3) * HP + (tap % 3)) * 32;
         }
-        if (wid >= 4 && k + 1 < nloc) halo_store(k + 1, (k + 1) & 1);
+        const int b_lane = fr * 64 + ((fq ^ c8_g(fr >> 2)) << 4);
+        half8 fa[2][2], fb[2][5];                               // fragments of k-step t in set t & 1 (read while the previous step's MFMAs run)
+        auto read_frags = [&](const char* wst, const char* hb, int t, int set) {
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) fb[set][jj] = as_half8(*reinterpret_cast<const uint4*>(wst + t * 5120 + jj * 1024));
+            fa[set][0] = as_half8(*reinterpret_cast<const uint4*>(hb + a_lane0 + toff[t]));
+            fa[set][1] = as_half8(*reinterpret_cast<const uint4*>(hb + a_lane1 + toff[t]));
+        };
+        for (int k = 0; k < nloc; ++k) {
+            __builtin_amdgcn_s_barrier();
+            const char* wst = wring + (k & (C8_RING - 1)) * C8_WSTAGE + b_lane;
+            const char* hb = halo + ((k >> 1) & 1) * GROUP_B + (k & 1) * PLANE_B;
+            read_frags(wst, hb, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < 5) read_frags(wst, hb, t + 1, (t + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);              // (all reads of the next step go out before this step's MFMAs: hipcc otherwise sinks them behind)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 5; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[t & 1][jj], fa[t & 1][i], acc[i][jj], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 
-    // ------------------------------------------------------------------------------------------ partial sums -> HBM (write-through)
-    float* const slab0 = p.partial + (long long)j * (RT * 5 * 256);
-    const long long slab_stride = (long long)NTN * (RT * 5 * 256);
+    C8_STAMP(2);
+    // ------------------------------------------------------------------------------------------ epilogue
+    const long long tile = (long long)tm * NTN + j;
+    const int cpg_o = p.N / 32;
+    float4* const scratch = reinterpret_cast<float4*>(wring);   // [8 parts][320 items]: the ring is quiet by the time it is written
+    // one float4 item = four consecutive output channels of one pixel: bias / time-embedding row / residual, fp16 store, and the statistics of
+    // what was stored per channel PAIR (a group boundary never splits a pair: N / 32 is even)
+    auto finish_item = [&](int r, int jj, int li, f32x4 v, half4 hb4, half4 he4, half4 hr4) {
+        const long long m = (long long)tm * 128 + r * 16 + (li & 15);
+        const int n = j * C8_BN + jj * 16 + (li >> 4) * 4;
+        half4 o;
+        float f[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = v[e] + (float)hb4[e] + (float)he4[e] + (float)hr4[e];
+            o[e] = (half_t)t;
+            f[e] = (float)o[e];
+        }
+        *reinterpret_cast<half4*>(p.C + m * p.ldc + n) = o;
+        scratch[r * ITEMS + jj * 64 + li] = make_float4(f[0] + f[1], f[0] * f[0] + f[1] * f[1], f[2] + f[3], f[2] * f[2] + f[3] * f[3]);
+    };
+    auto operands = [&](int r, int jj, int li, half4& hb4, half4& he4, half4& hr4) {
+        const long long m = (long long)tm * 128 + r * 16 + (li & 15);
+        const int n = j * C8_BN + jj * 16 + (li >> 4) * 4;
+        // (always loads: conv8_launch points an absent operand at a page of zeros with a zero row stride)
+        hb4 = *reinterpret_cast<const half4*>(p.bias_n + n);
+        he4 = *reinterpret_cast<const half4*>(p.rowvec + (m / p.rows_per_vec) * p.ldrv + n);
+        hr4 = *reinterpret_cast<const half4*>(p.R + m * p.ldr + n);
+    };
+    // GroupNorm partial statistics of part r: (image, 16-pixel chunk, group), fixed order; one wave per (part, group)
+    auto part_stats = [&](int r, int grp) {
+        float a = 0.f, b = 0.f;
+        for (int e = lane; e < ITEMS; e += 64) {
+            const int col = (e >> 6) * 16 + ((e & 63) >> 4) * 4;
+            const float4 t = scratch[r * ITEMS + e];
+            if (col / cpg_o == grp) {
+                a += t.x;
+                b += t.y;
+            }
+            if ((col + 2) / cpg_o == grp) {
+                a += t.z;
+                b += t.w;
+            }
+        }
+        a = wave_sum(a);
+        b = wave_sum(b);
+        if (lane == 0) {
+            const long long row = (long long)tm * 128 + r * 16;
+            const int img = (int)(row / HW), chunk = (int)(row - (long long)img * HW) >> 4;
+            float* o = p.gn_part + (((long long)img * (HW / 16) + chunk) * 32 + (j * C8_BN) / cpg_o + grp) * 2;
+            o[0] = a;
+            o[1] = b;
+        }
+    };
+    const int ngrp = C8_BN / cpg_o;                             // groups of this N tile: 2 / 4 / 8
+
+    if (S == 1) {   // no split: every consumer wave finishes its own 32 rows straight from the accumulators
+        __syncthreads();                                        // (everybody is done with the ring: scratch lives there)
+        if (wid < 4) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                half4 hb4[5], he4[5], hr4[5];
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj) operands(wid * 2 + i, jj, lane, hb4[jj], he4[jj], hr4[jj]);
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj) finish_item(wid * 2 + i, jj, lane, acc[i][jj], hb4[jj], he4[jj], hr4[jj]);
+            }
+        }
+        if (p.gn_part != nullptr) {
+            __syncthreads();
+            if (wid < 8)
+                for (int grp = 0; grp < ngrp; ++grp) part_stats(wid, grp);   // wave w: part w
+        }
+        C8_STAMP(5);
+        return;
+    }
+
+    // ---- partial sums -> HBM (write-through)
+    float* const slab0 = p.partial + tile * (8 * 5 * 256);
+    const long long slab_stride = (long long)TMS * NTN * (8 * 5 * 256);
     {
         float* mine = slab0 + (long long)s * slab_stride;
+        if (wid < 4) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jj = 0; jj < 5; ++jj) st16_sc1(mine + (((rt0 + i) * 5 + jj) * 64 + lane) * 4, acc[i][jj]);
+                for (int jj = 0; jj < 5; ++jj) st16_sc1(mine + (((wid * 2 + i) * 5 + jj) * 64 + lane) * 4, acc[i][jj]);
+        }
     }
     wait_vmcnt<0>();                                            // every storing wave drains its stores ...
     __syncthreads();                                            // ... before ONE lane signals for the workgroup
-    int* const cnt = p.sync + j * 4;                            // [0] arrivals, [1] claims, [2] leavers
+    C8_STAMP(3);
+    int* const cnt = p.sync + tile * 4;                         // [0] arrivals, [1] claims, [2] leavers
     if (tid == 0) {
         const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 1;
         if (t != S - 1) {                                       // not the last arriver: wait (bounded) until every slab of the tile is there
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(2);
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 200000ull) {   // 2 ms at 100 MHz: peers not resident — leave, the last arriver finishes
                     ok = 0;
                     break;
@@ -294,83 +516,74 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(const GemmParams p
     }
     __syncthreads();
     const bool take = flags[0] != 0;
+    C8_STAMP(4);
 
-    const int hw = WD * WD;
-    const int cpg_o = p.N / 32;
-    float2* const scratch = reinterpret_cast<float2*>(wring);   // the ring is quiet now
-    while (take) {
-        __syncthreads();                                        // (flags / scratch of the previous part are consumed)
-        if (tid == 0) flags[1] = __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // A claim = PC consecutive 16-row parts (PC = 8 / S for a split of 2 or 4: every workgroup then makes ONE round trip to the slabs).
+    // Every load of the claim goes out before the first wait: the epilogue operands, then the S slabs of every item; slabs are summed in
+    // slab order.  SS = the split as a compile-time constant (0: run-time S <= 16, clamped duplicates beyond it; further slabs one at a time).
+    auto do_claim = [&](auto SSc, auto PCc) {
+        constexpr int SS = decltype(SSc)::value, PC = decltype(PCc)::value;
+        constexpr int NIT = (PC * ITEMS + C8_THREADS - 1) / C8_THREADS, NL = SS ? SS : 16;
+        __syncthreads();                                        // (flags / scratch of the previous claim are consumed)
+        if (tid == 0) flags[1] = __hip_atomic_fetch_add(cnt + 1, PC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        const int r = flags[1];
-        if (r >= NP) break;
+        const int r0 = flags[1];                                // parts r0 .. r0 + PC - 1: rows 16 r .. 16 r + 15 of the patch
+        if (r0 >= 8) return false;
+        half4 hb4[NIT], he4[NIT], hr4[NIT];
+        f32x4 x[NIT][NL];
 #pragma unroll
-        for (int u = 0; u < (ITEMS + C8_THREADS - 1) / C8_THREADS; ++u) {
+        for (int u = 0; u < NIT; ++u) {
             const int idx = tid + C8_THREADS * u;
-            if (idx >= ITEMS) continue;
-            const int li = idx & 63, tj = idx >> 6;
-            const int jj = tj % 5, rtl = tj / 5;
-            const int rt = r * RTPP + rtl;
-            const float* base = slab0 + ((rt * 5 + jj) * 64 + li) * 4;
+            const int id = idx < PC * ITEMS ? idx : 0;
+            const int pr = id / ITEMS, it = id - pr * ITEMS;
+            const int li = it & 63, jj = it >> 6, r = r0 + pr;
+            operands(r, jj, li, hb4[u], he4[u], hr4[u]);
+            const float* base = slab0 + ((r * 5 + jj) * 64 + li) * 4;
+#pragma unroll
+            for (int q2 = 0; q2 < NL; ++q2) x[u][q2] = ld16_sc1(base + (long long)(SS ? q2 : (q2 < S ? q2 : S - 1)) * slab_stride);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);                      // (nothing that reads x moves above the wait)
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int idx = tid + C8_THREADS * u;
+            if (idx >= PC * ITEMS) continue;
+            const int pr = idx / ITEMS, it = idx - pr * ITEMS;
+            const int li = it & 63, jj = it >> 6, r = r0 + pr;
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            int sl = 0;
-            for (; sl + 4 <= S; sl += 4) {                      // four slabs per batch of loads, summed in slab order
-                f32x4 x[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) x[q] = ld16_sc1(base + (long long)(sl + q) * slab_stride);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])::"memory");
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v += x[q];
+            for (int q2 = 0; q2 < NL; ++q2)
+                if (SS || q2 < S) v += x[u][q2];
+            if (!SS) {
+                for (int sl = 16; sl < S; ++sl) {               // (run-time splits beyond 16: one slab at a time)
+                    f32x4 y = ld16_sc1(slab0 + ((r * 5 + jj) * 64 + li) * 4 + (long long)sl * slab_stride);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(y)::"memory");
+                    v += y;
+                }
             }
-            for (; sl < S; ++sl) {
-                f32x4 x = ld16_sc1(base + (long long)sl * slab_stride);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)::"memory");
-                v += x;
-            }
-            const int m = rt * 16 + (li & 15), n = j * C8_BN + jj * 16 + (li >> 4) * 4;
-            const half4 hb4 = p.bias_n != nullptr ? *reinterpret_cast<const half4*>(p.bias_n + n) : (half4){0, 0, 0, 0};
-            const half4 he4 = p.rowvec != nullptr ? *reinterpret_cast<const half4*>(p.rowvec + (long long)(m / p.rows_per_vec) * p.ldrv + n) : (half4){0, 0, 0, 0};
-            const half4 hr4 = p.R != nullptr ? *reinterpret_cast<const half4*>(p.R + (long long)m * p.ldr + n) : (half4){0, 0, 0, 0};
-            half4 o;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = v[e] + (float)hb4[e] + (float)he4[e] + (float)hr4[e];
-                o[e] = (half_t)t;
-                const float f = (float)o[e];
-                s1 += f;
-                s2 += f * f;
-            }
-            *reinterpret_cast<half4*>(p.C + (long long)m * p.ldc + n) = o;
-            scratch[idx] = make_float2(s1, s2);
+            finish_item(r, jj, li, v, hb4[u], he4[u], hr4[u]);
         }
-        if (p.gn_part != nullptr) {   // GroupNorm partial statistics of the output: (image, row part, group), fixed order
+        if (p.gn_part != nullptr) {
             __syncthreads();
-            const int ngrp = C8_BN / cpg_o;
-            if (wid < ngrp) {
-                float a = 0.f, b = 0.f;
-                for (int e = lane; e < ITEMS; e += 64) {
-                    const int tj = e >> 6;
-                    const int col = (tj % 5) * 16 + ((e & 63) >> 4) * 4;
-                    if (col / cpg_o == wid) {
-                        const float2 t = scratch[e];
-                        a += t.x;
-                        b += t.y;
-                    }
-                }
-                a = wave_sum(a);
-                b = wave_sum(b);
-                if (lane == 0) {
-                    const int row = r * RTPP * 16;
-                    const int img = row / hw, chunk = (row - img * hw) / (RTPP * 16);
-                    float* o = p.gn_part + (((long long)img * (hw / (RTPP * 16)) + chunk) * 32 + (j * C8_BN) / cpg_o + wid) * 2;
-                    o[0] = a;
-                    o[1] = b;
-                }
-            }
+            for (int pi = wid; pi < PC * ngrp; pi += 12) part_stats(r0 + pi / ngrp, pi % ngrp);
         }
+        return true;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I4 = std::integral_constant<int, 4>;
+    using I8 = std::integral_constant<int, 8>;
+    using I16 = std::integral_constant<int, 16>;
+    if (take) {
+        if (S == 2) while (do_claim(I2{}, I4{})) {}
+        else if (S == 4) while (do_claim(I4{}, I2{})) {}
+        else if (S == 8) while (do_claim(I8{}, I1{})) {}
+        else if (S == 16) while (do_claim(I16{}, I1{})) {}
+        else while (do_claim(I0{}, I1{})) {}
     }
     __syncthreads();
+    C8_STAMP(5);
     if (tid == 0) {   // the last workgroup of the tile to leave resets the counters for the next launch
         const int e = __hip_atomic_fetch_add(cnt + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (e == S - 1) {
@@ -381,53 +594,98 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_kernel(const GemmParams p
     }
 }
 
-template <int WD, int IMGS>
+template <int WD>
 constexpr int c8_lds_bytes() {
-    return C8_RING * C8_WSTAGE + 2 * IMGS * (WD + 2) * (WD + 2) * 32 + 2 * IMGS * C8_MAXCW * 4 + IMGS * 32 * 4 + 64;
+    constexpr int TI = WD == 8 ? 2 : 1, RH = WD == 8 ? 8 : 128 / WD;
+    return C8_RING * C8_WSTAGE + 4 * TI * (RH + 2) * (WD + 2) * 32 + 2 * TI * C8_MAXCW * 4 + 4 * C8_MAXPAIR * 2 * 4 + 64;
 }
 
-template <int WD, int IMGS, bool GN, bool UP>
+template <int WD, bool GN, bool UP>
 void c8_launch(const GemmParams& p, hipStream_t stream) {
-    constexpr int lds = c8_lds_bytes<WD, IMGS>();
+    constexpr int lds = c8_lds_bytes<WD>();
+    static_assert(lds <= 163840, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8_kernel<WD, IMGS, GN, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8_kernel<WD, GN, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv8_kernel<WD, IMGS, GN, UP>), dim3((p.N / C8_BN) * p.c8_S), dim3(C8_THREADS), lds, stream, p);
+    const int groups = (p.N / C8_BN) * p.c8_S, tms = p.M / 128;
+    hipLaunchKernelGGL((conv8_kernel<WD, GN, UP>), dim3((unsigned)(groups * tms)), dim3(C8_THREADS), lds, stream, p);
+}
+
+template <int WD>
+void c8_dispatch(const GemmParams& p, hipStream_t stream) {
+    if (p.Hv == 2 * p.Hs) c8_launch<WD, false, true>(p, stream);
+    else if (p.gn_in_part != nullptr || p.gn_scale != nullptr) c8_launch<WD, true, false>(p, stream);
+    else c8_launch<WD, false, false>(p, stream);
+}
+
+// [O][tap][I] (the general layout, ld_op_repack_conv / PK_CONV3) -> conv8's stage images: chunk (j, ss, t, n, pc) of 8 halfs holds
+// W[80 j + n][tap = 2 t + (fq >> 1)][16 ss + 8 (fq & 1) .. + 8] with fq = pc ^ g(n >> 2), zeros for the tenth tap
+__global__ __launch_bounds__(256) void conv8_repack_kernel(const half_t* __restrict__ w, int N, int Cin, uint4* __restrict__ dst) {
+    const int nsub = Cin >> 4;
+    const long long total = (long long)(N / C8_BN) * nsub * 1600;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (long long)gridDim.x * blockDim.x) {
+        const int within = (int)(c % 1600);
+        const long long st = c / 1600;
+        const int ss = (int)(st % nsub), j = (int)(st / nsub);
+        const int t = within / 320, rem = within - 320 * t;
+        const int n = rem >> 2, pc = rem & 3;
+        const int fql = pc ^ c8_g(n >> 2);
+        const int tap = 2 * t + (fql >> 1), cc = fql & 1;
+        dst[c] = tap < 9 ? ld16(w + ((long long)(j * C8_BN + n) * 9 + tap) * Cin + ss * 16 + cc * 8) : zero16();
+    }
 }
 
 }  // namespace
 
-// Does this convolution run on the row-resident kernel?  Fills the slab split.  (The caller provides p.partial and p.sync.)
+size_t conv8_weight_bytes(int N, int Cin) { return (size_t)(N / C8_BN) * (Cin / 16) * C8_WSTAGE; }
+bool conv8_weight_eligible(int N, int Cin) { return N > 0 && Cin > 0 && N % C8_BN == 0 && Cin % 32 == 0; }
+
+int conv8_repack_launch(const half_t* w, int N, int Cin, half_t* dst, hipStream_t stream) {
+    if (w == nullptr || dst == nullptr || !conv8_weight_eligible(N, Cin)) return LD_ERR_ARG;
+    const long long total = (long long)(N / C8_BN) * (Cin / 16) * 1600;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv8_repack_kernel, dim3(blocks), dim3(256), 0, stream, w, N, Cin, reinterpret_cast<uint4*>(dst));
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+// Does this convolution run on the row-resident kernel?  Fills the slab split.  (The caller provides p.W8, p.partial and p.sync.)
 bool conv8_plan(const GemmParams& p, int* S_out) {
     if (!(p.conv && p.ksize == 3 && p.stride == 1 && (p.pad < 0 || p.pad == 1) && p.batch == 1 && p.act == 0 && p.alpha == 1.0f && p.bias_m == nullptr &&
-          p.bm == 0 && p.bn == 0 && p.splitk == 0 && p.partial != nullptr && p.sync != nullptr && p.gn_scale == nullptr && p.stat_out == nullptr &&
-          p.ln_stat == nullptr))
+          p.bm == 0 && p.bn == 0 && p.splitk == 0 && p.W8 != nullptr && p.partial != nullptr && p.sync != nullptr && p.stat_out == nullptr && p.ln_stat == nullptr))
         return false;
     const bool same = p.Hv == p.Hs && p.Wv == p.Ws;
-    const bool up = p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws && p.C2 == 0 && p.gn_in_part == nullptr;
+    const bool gn = p.gn_in_part != nullptr || p.gn_scale != nullptr;
+    const bool up = p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws && p.C2 == 0 && !gn;
     if (!(same || up) || p.Ho != p.Hv || p.Wo != p.Wv || p.Ho != p.Wo) return false;
-    if (!(p.Wo == 8 || p.Wo == 16) || p.M != 2 * p.Wo * p.Wo) return false;             // two images (the CFG pair of a batch-1 step)
-    if (p.N % C8_BN || p.C1 % 16 || p.C2 % 16 || (p.N & 3) || p.ldc % 4 || (p.R != nullptr && p.ldr % 4) || (p.rowvec != nullptr && p.ldrv % 4)) return false;
+    if (!(p.Wo == 8 || p.Wo == 16 || p.Wo == 32 || p.Wo == 64) || p.M % 128 || p.M % (p.Wo * p.Wo)) return false;
+    if (p.N % C8_BN || p.C1 % 32 || p.C2 % 32 || (p.N & 3) || p.ldc % 4 || (p.R != nullptr && p.ldr % 4) || (p.rowvec != nullptr && p.ldrv % 4)) return false;
     if (p.n_valid > 0 && p.n_valid < p.N) return false;
-    const int Cin = p.C1 + p.C2, nsub = Cin / 16, ntn = p.N / C8_BN;
-    if (p.K != 9 * Cin || p.ldw != p.K) return false;
-    if (p.gn_in_part != nullptr && (Cin % 32 || p.gn_gamma == nullptr || p.gn_beta == nullptr || p.gn_in_P <= 0)) return false;
-    if (p.gn_part != nullptr && ((p.N / 32) % 4 || C8_BN % (p.N / 32))) return false;
-    if (p.gn_in_part != nullptr && C8_MAXCW / (Cin / 32) + 2 > 16) return false;        // groups one slab can touch (mean / rstd table)
-    int S = 256 / ntn;
-    if (S > nsub) S = nsub;
-    // every workgroup's slab must fit the scale / shift table and the weight stream must be worth splitting
+    const int Cin = p.C1 + p.C2, nsub = Cin / 16, ntn = p.N / C8_BN, tms = p.M / 128;
+    if (p.K != 9 * Cin) return false;
+    if (p.gn_scale != nullptr && p.gn_shift == nullptr) return false;
+    if (p.gn_scale == nullptr && p.gn_in_part != nullptr && (p.gn_gamma == nullptr || p.gn_beta == nullptr || p.gn_in_P <= 0 || p.gn_in_P > 256)) return false;
+    if (p.gn_part != nullptr && ((p.N / 32) & 1)) return false;
+    // the patches x N tiles must leave room for a split that fills the chip, and the split must keep the weight stream worth it
+    const long long tiles = (long long)tms * ntn;
+    if (tiles > 256 || tiles * 4 > LD_SYNC_INTS) return false;
+    int S = (int)(256 / tiles);
+    if (S > nsub / 2) S = nsub / 2;                                       // at least two sub-slabs per workgroup
     while (S > 1 && (size_t)S * p.M * p.N * sizeof(float) > p.partial_bytes) --S;
-    if (S < 1 || (nsub + S - 1) / S * 16 > C8_MAXCW) return false;
-    if (ntn * S < 128 || ntn * 4 > 256) return false;
+    if (S < 1 || (size_t)p.M * p.N * sizeof(float) > p.partial_bytes) return false;
+    const int cw = (nsub + S - 1) / S * 16;                                // widest slab
+    if (cw > C8_MAXCW) return false;
+    // (a slab that touches more (image, group) pairs than the in-kernel finalize holds needs the caller's scale / shift: conv8_needs_scale_shift)
+    if (p.gn_scale == nullptr && p.gn_in_part != nullptr && (p.Wo == 8 ? 2 : 1) * (cw / (Cin / 32) + 2) > C8_MAXPAIR) return false;
+    if (tiles * S < 96) return false;
     if (S_out) *S_out = S;
     return true;
 }
 
 // number of pixel chunks per image of the GroupNorm partials the kernel emits (GemmParams::gn_part) for this shape
-int conv8_gn_chunks(const GemmParams& p) { return p.Wo == 16 ? 8 : 4; }
+int conv8_gn_chunks(const GemmParams& p) { return p.Wo * p.Wo / 16; }
 
 int conv8_launch(const GemmParams& pin, hipStream_t stream) {
     GemmParams p = pin;
@@ -435,16 +693,26 @@ int conv8_launch(const GemmParams& pin, hipStream_t stream) {
     if (!conv8_plan(p, &S)) return LD_ERR_ARG;
     p.c8_S = S;
     p.pad = 1;
-    const bool gn = p.gn_in_part != nullptr;
-    const bool up = p.Hv == 2 * p.Hs;
-    if (p.Wo == 16) {
-        if (up) c8_launch<16, 2, false, true>(p, stream);
-        else if (gn) c8_launch<16, 2, true, false>(p, stream);
-        else c8_launch<16, 2, false, false>(p, stream);
-    } else {
-        if (up) c8_launch<8, 2, false, true>(p, stream);
-        else if (gn) c8_launch<8, 2, true, false>(p, stream);
-        else c8_launch<8, 2, false, false>(p, stream);
+#ifdef LD_AB_BUILD
+    p.dbg = getenv("LD_C8_STAMPS") != nullptr && p.partial_bytes > ((size_t)1 << 20);
+#endif
+    if (p.bias_n == nullptr || p.rowvec == nullptr || p.R == nullptr) {
+        static const half_t* zero_page = nullptr;
+        if (zero_page == nullptr) {
+            void* z = nullptr;
+            if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_c8_zero)) != hipSuccess) return LD_ERR_HIP;
+            zero_page = static_cast<const half_t*>(z);
+        }
+        if (p.N > 8192) return LD_ERR_SHAPE;
+        if (p.bias_n == nullptr) p.bias_n = zero_page;
+        if (p.rowvec == nullptr) { p.rowvec = zero_page; p.ldrv = 0; p.rows_per_vec = 1; }
+        if (p.R == nullptr) { p.R = zero_page; p.ldr = 0; }
+    }
+    switch (p.Wo) {
+        case 8: c8_dispatch<8>(p, stream); break;
+        case 16: c8_dispatch<16>(p, stream); break;
+        case 32: c8_dispatch<32>(p, stream); break;
+        default: c8_dispatch<64>(p, stream); break;
     }
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }

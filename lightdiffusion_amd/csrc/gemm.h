@@ -73,6 +73,7 @@ struct GemmParams {
     const half_t* gn_gamma = nullptr;
     const half_t* gn_beta = nullptr;
     float gn_eps = 0.f;
+    const half_t* W8 = nullptr;  // the weights in conv8's own layout (conv8_repack_launch): required for that kernel
     //   its in-launch reduction of the channel-slab partial sums needs >= 4 * (N / 80) zeroed ints that it leaves zeroed (self-resetting)
     int* sync = nullptr;
     int c8_S = 0;                // (internal) slab split chosen by conv8_plan
@@ -85,7 +86,11 @@ struct GemmParams {
 bool conv8_plan(const GemmParams& p, int* S_out);
 int conv8_gn_chunks(const GemmParams& p);
 int conv8_launch(const GemmParams& p, hipStream_t stream);
-#define LD_SYNC_INTS 256         // ints a caller provides behind GemmParams::sync
+// conv8's weight layout: [N / 80][Cin / 16][one 25 600-byte ring-stage image] from the general [O][ky][kx][I] layout
+bool conv8_weight_eligible(int N, int Cin);
+size_t conv8_weight_bytes(int N, int Cin);
+int conv8_repack_launch(const half_t* w_okki, int N, int Cin, half_t* dst, hipStream_t stream);
+#define LD_SYNC_INTS 1024        // ints a caller provides behind GemmParams::sync
 
 bool gemm_ln_fold_available();   // the kernels that implement stat_out / ln_stat are the ones gemm_launch will pick
 const char* gemm_last_kernel_name();   // kernel instantiation the calling thread's last gemm_launch dispatched

@@ -2453,9 +2453,12 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     // ---- conv8 (row-resident, weights streamed once, in-launch slab reduction): the two-image 16x16 / 8x8 levels of a batch-1 step
     if (conv8_plan(p, nullptr)) {
-        const bool up8 = p.Hv == 2 * p.Hs;
-        t_last_kernel = p.Wo == 16 ? (up8 ? "conv8_kernel<W16,up>" : p.gn_in_part ? "conv8_kernel<W16,groupnorm>" : "conv8_kernel<W16>")
-                                   : (up8 ? "conv8_kernel<W8,up>" : p.gn_in_part ? "conv8_kernel<W8,groupnorm>" : "conv8_kernel<W8>");
+        const bool up8 = p.Hv == 2 * p.Hs, gn8 = p.gn_in_part != nullptr || p.gn_scale != nullptr;
+        static const char* names[4][3] = {{"conv8_kernel<W8>", "conv8_kernel<W8,groupnorm>", "conv8_kernel<W8,up>"},
+                                          {"conv8_kernel<W16>", "conv8_kernel<W16,groupnorm>", "conv8_kernel<W16,up>"},
+                                          {"conv8_kernel<W32>", "conv8_kernel<W32,groupnorm>", "conv8_kernel<W32,up>"},
+                                          {"conv8_kernel<W64>", "conv8_kernel<W64,groupnorm>", "conv8_kernel<W64,up>"}};
+        t_last_kernel = names[p.Wo == 8 ? 0 : p.Wo == 16 ? 1 : p.Wo == 32 ? 2 : 3][up8 ? 2 : gn8 ? 1 : 0];
         if (p.gn_part != nullptr && p.gn_part_done != nullptr) *p.gn_part_done = conv8_gn_chunks(p);
         return conv8_launch(p, stream);
     }

@@ -300,7 +300,9 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ 
 }  // namespace
 
 size_t groupnorm_workspace_bytes(int n_img, int HW) {
-    const int P = gn_num_chunks(n_img, HW);
+    int P = gn_num_chunks(n_img, HW);
+    const int p8 = HW / 16 < 256 ? HW / 16 : 256;               // a producer's epilogue may write 16-pixel chunks (conv8: HW / 16 per image, up to 64 x 64 images)
+    if (p8 > P) P = p8;
     return (size_t)n_img * P * 32 * 2 * sizeof(float);
 }
 

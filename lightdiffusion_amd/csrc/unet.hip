@@ -74,6 +74,20 @@ struct ld_unet {
     int last_launches = 0;
     double last_flops = 0.0;
     int* sync_ws = nullptr;        // LD_SYNC_INTS zeroed ints for the in-launch reductions (gemm.h GemmParams::sync)
+    // derived copies of the 3x3 convolution weights in the row-resident kernel's layout (conv8.hip), re-derived with the LayerNorm folds
+    struct W8 { int slot, N, Cin; size_t off; };
+    std::vector<W8> w8_list;
+    std::vector<long long> w8_of_slot;   // byte offset into w8_base per parameter slot, -1: none
+    char* w8_base = nullptr;
+    size_t w8_bytes = 0;
+    const half_t* w8(int slot) const {
+        return (w8_base != nullptr && slot >= 0 && slot < (int)w8_of_slot.size() && w8_of_slot[slot] >= 0) ? reinterpret_cast<const half_t*>(w8_base + w8_of_slot[slot]) : nullptr;
+    }
+    void want_w8(int slot, int N, int Cin) {
+        if (!conv8_weight_eligible(N, Cin)) return;
+        w8_list.push_back({slot, N, Cin, w8_bytes});
+        w8_bytes += (conv8_weight_bytes(N, Cin) + 255) / 256 * 256;
+    }
     Timing timing;
     bool want_timing = false;
     char* fold_base = nullptr;     // LN-folded copies of the LN-consuming projections (see StW)
@@ -100,10 +114,12 @@ int add_res(ld_unet* u, const std::string& p, int cin, int cout) {
     r.gn1_b = t.add(p + ".in_layers.0.bias", PK_VEC, {cin});
     r.c1_w = t.add(p + ".in_layers.2.weight", PK_CONV3, {cout, cin, 3, 3});
     r.c1_b = t.add(p + ".in_layers.2.bias", PK_VEC, {cout});
+    u->want_w8(r.c1_w, cout, cin);
     r.gn2_g = t.add(p + ".out_layers.0.weight", PK_VEC, {cout});
     r.gn2_b = t.add(p + ".out_layers.0.bias", PK_VEC, {cout});
     r.c2_w = t.add(p + ".out_layers.3.weight", PK_CONV3, {cout, cout, 3, 3});
     r.c2_b = t.add(p + ".out_layers.3.bias", PK_VEC, {cout});
+    u->want_w8(r.c2_w, cout, cout);
     if (cin != cout) {
         r.sk_w = t.add(p + ".skip_connection.weight", PK_MAT, {cout, cin, 1, 1});
         r.sk_b = t.add(p + ".skip_connection.bias", PK_VEC, {cout});
@@ -234,7 +250,10 @@ int build(ld_unet* u) {
                 L.push_back({L_ST, add_st(u, S("output_blocks.%d.%d", idx, j), ch)});
                 ++j;
             }
-            if (lvl && i == c.num_res_blocks[lvl]) L.push_back({L_UP, add_conv(u, S("output_blocks.%d.%d.conv", idx, j), ch, ch)});
+            if (lvl && i == c.num_res_blocks[lvl]) {
+                L.push_back({L_UP, add_conv(u, S("output_blocks.%d.%d.conv", idx, j), ch, ch)});
+                u->want_w8(u->convs.back().w, ch, ch);
+            }
             u->out_blocks.push_back(L);
             ++idx;
         }
@@ -292,6 +311,7 @@ struct Run {
         p.A = x1; p.A2 = x2; p.C1 = C1; p.C2 = C2;
         p.Hs = Hs; p.Ws = Ws; p.Hv = Hv; p.Wv = Wv; p.Ho = Ho; p.Wo = Wo; p.stride = stride;
         p.W = P(wslot); p.ldw = ksize * ksize * (C1 + C2);
+        p.W8 = ksize == 3 ? u->w8(wslot) : nullptr;
         p.M = n * Ho * Wo; p.N = cout; p.K = ksize * ksize * (C1 + C2);
         p.bias_n = P(bslot);
         p.rowvec = rowvec; p.rows_per_vec = Ho * Wo; p.ldrv = ldrv;
@@ -336,6 +356,7 @@ struct Run {
             p.A = a1; p.A2 = a2; p.C1 = c1; p.C2 = c2;
             p.Hs = H; p.Ws = W; p.Hv = H; p.Wv = W; p.Ho = H; p.Wo = W; p.stride = 1;
             p.W = P(wslot); p.ldw = 9 * (c1 + c2);
+            p.W8 = u->w8(wslot);
             p.M = n * H * W; p.N = r.cout; p.K = 9 * (c1 + c2);
             p.bias_n = P(bslot);
             p.rowvec = rowvec; p.rows_per_vec = H * W; p.ldrv = ldrv;
@@ -555,14 +576,30 @@ int fold_layernorms(ld_unet* u, hipStream_t stream) {
     return LD_OK;
 }
 
+// the row-resident kernel's copies of the 3x3 convolution weights (conv8.hip), once per weight load
+int derive_conv8_weights(ld_unet* u, hipStream_t stream) {
+    for (const ld_unet::W8& w : u->w8_list) {
+        const int st = conv8_repack_launch(u->pt.ptr(w.slot), w.N, w.Cin, reinterpret_cast<half_t*>(u->w8_base + w.off), stream);
+        if (st != LD_OK) return st;
+    }
+    return LD_OK;
+}
+
 // `pair`: classifier-free-guidance pair (ld_unet_forward_pair).  x / sigma hold n / 2 samples; the batch is [uncond x n/2 ; cond x n/2] of the SAME latents
 // (what calc_cond_batch feeds the model: cat([x, x]), LD.py:2515-2547); the resident context has n rows.  The layers in front of the first
 // cross-attention run once on n / 2 samples (Run::pair_pending), everything else on n.  out: n samples.
 int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float* out, int n, int h, int w, int eps_only, hipStream_t stream,
                 size_t* dry_peak = nullptr, bool pair = false) {
-    if (!dry && u->ln_fold && u->fold_dirty) {
-        const int st = fold_layernorms(u, stream);
-        if (st != LD_OK) return st;
+    if (!dry && u->fold_dirty) {
+        if (u->w8_base != nullptr) {
+            const int st = derive_conv8_weights(u, stream);
+            if (st != LD_OK) return st;
+        }
+        if (u->ln_fold) {
+            const int st = fold_layernorms(u, stream);
+            if (st != LD_OK) return st;
+        }
+        u->fold_dirty = false;
     }
     if (pair && (n & 1)) return LD_ERR_SHAPE;
     Run R;
@@ -744,6 +781,9 @@ int ld_unet_create(const ld_unet_config* cfg, ld_unet** out) {
             ls[i] = (float)log(sqrt((1.0 - ac) / ac));
         }
     }
+    u->w8_of_slot.assign(u->pt.slots.size(), -1);
+    for (const ld_unet::W8& w : u->w8_list) u->w8_of_slot[w.slot] = (long long)w.off;
+    if (u->w8_bytes > 0 && hipMalloc((void**)&u->w8_base, u->w8_bytes) != hipSuccess) u->w8_base = nullptr;   // (without the copies the general kernels run)
     u->ln_fold = gemm_ln_fold_available();
     if (u->ln_fold && u->fold_bytes > 0 && hipMalloc((void**)&u->fold_base, u->fold_bytes) != hipSuccess) {
         u->pt.destroy();
@@ -768,6 +808,7 @@ void ld_unet_destroy(ld_unet* u) {
     if (u->ws_base) (void)hipFree(u->ws_base);
     if (u->log_sigmas) (void)hipFree(u->log_sigmas);
     if (u->sync_ws) (void)hipFree(u->sync_ws);
+    if (u->w8_base) (void)hipFree(u->w8_base);
     if (u->fold_base) (void)hipFree(u->fold_base);
     delete u;
 }
@@ -791,7 +832,7 @@ int ld_unet_load_param(ld_unet* u, const char* name, const void* src, int dtype,
 }
 
 size_t ld_unet_workspace_bytes(const ld_unet* u) { return u ? u->ws_bytes : 0; }
-size_t ld_unet_weight_bytes(const ld_unet* u) { return u ? u->pt.bytes + (u->fold_base ? u->fold_bytes : 0) : 0; }
+size_t ld_unet_weight_bytes(const ld_unet* u) { return u ? u->pt.bytes + (u->fold_base ? u->fold_bytes : 0) + (u->w8_base ? u->w8_bytes : 0) : 0; }
 
 int ld_unet_reserve(ld_unet* u, int max_n, int max_h, int max_w, int max_tok) {
     if (u == nullptr || max_n < 1 || max_h < 1 || max_w < 1 || max_tok < 1) return LD_ERR_ARG;

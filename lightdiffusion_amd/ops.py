@@ -115,7 +115,7 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]
     ho = (hv - 1) // stride + 1 if ksize == 3 else hv
     wo = (wv - 1) // stride + 1 if ksize == 3 else wv
     y = torch.empty(n, ho, wo, cout, dtype=torch.float16, device=x.device)
-    ws = _ws(64 << 20, x.device)
+    ws = _ws(192 << 20, x.device)
     check(lib().ld_op_conv(_p(x), c1, _p(x2), c2, n, h, w, hv, wv, stride, ksize, _p(w_packed), _p(bias), _p(rowvec), _p(residual),
                            _p(y), cout, _p(ws), ws.numel(), _stream()), "ld_op_conv")
     return y

@@ -71,6 +71,30 @@ def test_config5_unet_128x128(sd15_unet, n):
     assert abs(sd15_unet.last_flops / n - 4674e9) / 4674e9 < 0.03      # 4 674 GFLOP per eval at 128x128
 
 
+def test_config5_forward_pair_128x128_batch4(sd15_unet):
+    """The route bench.py times for config #5 (LD.py:10585-10603 through calc_cond_batch, LD.py:2515-2547): ld_unet_forward_pair at nb = 4 on 128x128
+    latents — conv_in, the first ResBlock and the first transformer's self-attention (L = 16384) evaluated once on 4 samples, the rest on 8.
+    The golden's two samples carry different x, so pair i runs x_{o_i} twice against contexts [ctx_{1-o_i}, ctx_{o_i}]: the cond half must be the
+    reference's denoised row o_i; with the golden's own context in BOTH halves the uncond half must be it too."""
+    g = load_golden("unet_sd15_128x128")
+    order = [0, 1, 1, 0]
+    x = torch.stack([g["x"][i] for i in order]).to(DEV).contiguous()
+    s = torch.stack([g["sigma"][i] for i in order]).to(DEV).contiguous()
+    sd15_unet._ensure(8, 128, 128, 77)
+    sd15_unet.set_context(torch.stack([g["ctx"][1 - i] for i in order] + [g["ctx"][i] for i in order]))
+    den = sd15_unet.forward_pair(x, s).cpu()
+    assert den.shape == (8, 4, 128, 128) and torch.isfinite(den).all()
+    for row, src in enumerate(order):
+        assert rel_l2(den[4 + row], g["denoised"][src]) < UNET_TOL, row
+    sd15_unet.set_context(torch.stack([g["ctx"][i] for i in order] * 2))
+    den2 = sd15_unet.forward_pair(x, s).cpu()
+    for row, src in enumerate(order):
+        assert rel_l2(den2[row], g["denoised"][src]) < UNET_TOL and rel_l2(den2[4 + row], g["denoised"][src]) < UNET_TOL, row
+    # against the plain forward on the duplicated batch: two fp16 evaluations whose tile / split choices follow the row count
+    full = sd15_unet.forward(torch.cat([x, x]).contiguous(), torch.cat([s, s]).contiguous()).cpu()
+    assert rel_l2(den2, full) < 2e-3
+
+
 @pytest.mark.parametrize("hw,sub", [(64, 4), (128, 8)])
 def test_vae_decode_512_and_1024(hw, sub):
     """SD1.5 VAE decoder at 64x64 / 128x128 latents (512^2 / 1024^2 images: the [256,512,512] / [128,1024,1024] tensors of

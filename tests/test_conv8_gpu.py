@@ -39,12 +39,17 @@ def nchw(x):
 # (h = w, c1, c2, cout, time-embedding row, residual): every ResBlock convolution of SD1.5's 16x16 / 8x8 levels and the middle block at
 # UNet batch 2 — in_layers of the down path (640 -> 1280, 1280 -> 1280), of the up path (concat 1280 + 1280 / 1280 + 640: groups of 80 / 60
 # channels, the second one straddling the 16-channel sub-slabs AND the source boundary), out_layers (residual = skip)
-@pytest.mark.parametrize("hw,c1,c2,cout,rv,res", [
-    (16, 1280, 0, 1280, True, False), (16, 1280, 0, 1280, False, True), (16, 640, 0, 1280, True, False),
-    (16, 1280, 1280, 1280, True, False), (16, 1280, 640, 1280, True, True),
-    (8, 1280, 0, 1280, True, True), (8, 1280, 1280, 1280, True, False), (8, 1280, 0, 640, False, False)])
-def test_groupnorm_silu_conv_row_resident(ops, hw, c1, c2, cout, rv, res):
-    n, h, w = 2, hw, hw
+# and the 32x32 / 64x64 levels (patches of four / two image rows; at 64x64 one workgroup sweeps all of K and the scale / shift tables come from
+# gn_finalize_kernel), plus the 8x8 level at UNet batch 16 (eight two-image patches)
+@pytest.mark.parametrize("n,hw,c1,c2,cout,rv,res", [
+    (2, 16, 1280, 0, 1280, True, False), (2, 16, 1280, 0, 1280, False, True), (2, 16, 640, 0, 1280, True, False),
+    (2, 16, 1280, 1280, 1280, True, False), (2, 16, 1280, 640, 1280, True, True),
+    (2, 8, 1280, 0, 1280, True, True), (2, 8, 1280, 1280, 1280, True, False), (2, 8, 1280, 0, 640, False, False),
+    (2, 32, 640, 0, 640, True, True), (2, 32, 320, 0, 640, True, False), (2, 32, 640, 320, 640, True, False), (2, 32, 1280, 640, 640, False, True),
+    (2, 64, 320, 0, 320, True, True), (2, 64, 320, 320, 320, True, False), (2, 64, 640, 320, 320, False, False),
+    (16, 8, 1280, 0, 1280, True, True), (4, 16, 1280, 0, 1280, True, False), (1, 16, 640, 0, 640, False, False)])
+def test_groupnorm_silu_conv_row_resident(ops, n, hw, c1, c2, cout, rv, res):
+    h, w = hw, hw
     x1 = r16((n, c1, h, w), 201, 2.0) + 0.5
     x2 = (r16((n, c2, h, w), 202) - 1.0) if c2 else None
     cin = c1 + c2
@@ -71,12 +76,14 @@ def test_groupnorm_silu_conv_row_resident(ops, hw, c1, c2, cout, rv, res):
         assert torch.equal(y, y2)
 
 
-@pytest.mark.parametrize("hw,cin,cout,up,rv,res", [
-    (16, 1280, 1280, True, False, False),     # Upsample1 of the 8x8 level: nearest 2x inside the halo loader
-    (16, 1280, 1280, False, True, True),      # plain (no GroupNorm) route
-    (8, 1280, 1280, False, False, True)])
-def test_conv_row_resident(ops, hw, cin, cout, up, rv, res):
-    n = 2
+@pytest.mark.parametrize("n,hw,cin,cout,up,rv,res", [
+    (2, 16, 1280, 1280, True, False, False),     # Upsample1 of the 8x8 level: nearest 2x inside the halo loader
+    (2, 32, 1280, 1280, True, False, False),     # ... of the 16x16 level
+    (2, 64, 640, 640, True, False, False),       # ... of the 32x32 level
+    (2, 16, 1280, 1280, False, True, True),      # plain (no GroupNorm) route
+    (2, 8, 1280, 1280, False, False, True),
+    (2, 64, 320, 320, False, True, False)])
+def test_conv_row_resident(ops, n, hw, cin, cout, up, rv, res):
     hs = hw // 2 if up else hw
     x = r16((n, cin, hs, hs), 211)
     wt, b = r16((cout, cin, 3, 3), 212, 1 / math.sqrt(9 * cin)), r16((cout,), 213, 0.1)
