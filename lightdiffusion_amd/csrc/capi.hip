@@ -82,18 +82,19 @@ int ld_op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int
     p.C = (half_t*)y; p.ldc = cout;
     p.partial = (float*)ws;
     p.partial_bytes = ws ? ws_bytes : 0;
-    if (ws != nullptr && ksize == 3 && conv8_weight_eligible(cout, c1 + c2) && ws_bytes > 1024 + align256(conv8_weight_bytes(cout, c1 + c2)) + ((size_t)8 << 20)) {
+    constexpr size_t sync_b = LD_SYNC_INTS * sizeof(int);
+    if (ws != nullptr && ksize == 3 && conv8_weight_eligible(cout, c1 + c2) && ws_bytes > sync_b + align256(conv8_weight_bytes(cout, c1 + c2)) + ((size_t)8 << 20)) {
         // row-resident kernel (conv8.hip): the head of a roomy scratch buffer holds the (zeroed) counters of its in-launch reduction and a
         // copy of the weights in its layout, made per call here (the UNet executor keeps that copy resident)
         GemmParams c8 = p;
         const size_t w8b = align256(conv8_weight_bytes(cout, c1 + c2));
         c8.sync = (int*)ws;
-        c8.W8 = (const half_t*)((char*)ws + 1024);
-        c8.partial = (float*)((char*)ws + 1024 + w8b);
-        c8.partial_bytes = ws_bytes - 1024 - w8b;
+        c8.W8 = (const half_t*)((char*)ws + sync_b);
+        c8.partial = (float*)((char*)ws + sync_b + w8b);
+        c8.partial_bytes = ws_bytes - sync_b - w8b;
         if (conv8_plan(c8, nullptr)) {
-            if (hipMemsetAsync(ws, 0, LD_SYNC_INTS * sizeof(int), (hipStream_t)stream) != hipSuccess) return LD_ERR_HIP;
-            const int st = conv8_repack_launch((const half_t*)wt, cout, c1 + c2, (half_t*)((char*)ws + 1024), (hipStream_t)stream);
+            if (hipMemsetAsync(ws, 0, sync_b, (hipStream_t)stream) != hipSuccess) return LD_ERR_HIP;
+            const int st = conv8_repack_launch((const half_t*)wt, cout, c1 + c2, (half_t*)((char*)ws + sync_b), (hipStream_t)stream);
             if (st != LD_OK) return st;
             return gemm_launch(c8, (hipStream_t)stream);
         }
@@ -111,7 +112,7 @@ int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, 
                          const void* wt, const void* bias, const void* rowvec, const void* residual, void* y, int cout, void* ws, size_t ws_bytes,
                          void* stream_) {
     // GroupNorm(32) + SiLU + 3x3 convolution (stride 1, pad 1): the reference's ResBlock1.in_layers / out_layers (LD.py:5224-5262).
-    // On the halo-tile kernel the normalisation is fused into the convolution's A operand; otherwise two-pass GroupNorm, then the conv.
+    // On the halo-tile kernel with one N tile the normalisation is fused into the convolution's A operand; otherwise two-pass GroupNorm, then the conv.
     if (x1 == nullptr || gamma == nullptr || beta == nullptr || wt == nullptr || y == nullptr || ws == nullptr) return LD_ERR_ARG;
     if (ws_bytes < ld_op_groupnorm_conv_ws_bytes(c1, c2, n, h, w, cout)) return LD_ERR_ARG;
     hipStream_t stream = (hipStream_t)stream_;
@@ -138,27 +139,6 @@ int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, 
     p.R = (const half_t*)residual; p.ldr = cout;
     p.C = (half_t*)y; p.ldc = cout;
     p.partial = (float*)q; p.partial_bytes = (size_t)96 << 20;
-    {   // row-resident kernel (conv8.hip): statistics pass, then the convolution finishes and applies the normalisation itself
-        GemmParams c8 = p;
-        c8.sync = sync;
-        c8.W8 = w8;
-        c8.gn_in_part = part; c8.gn_in_P = gn_num_chunks(n, HW);
-        c8.gn_gamma = (const half_t*)gamma; c8.gn_beta = (const half_t*)beta; c8.gn_eps = eps; c8.gn_silu = 1;
-        bool direct = conv8_plan(c8, nullptr), tables = false;
-        if (!direct) {
-            c8.gn_scale = scale; c8.gn_shift = shift;
-            tables = conv8_plan(c8, nullptr);
-        }
-        if (direct || tables) {
-            if (hipMemsetAsync(sync, 0, LD_SYNC_INTS * sizeof(int), stream) != hipSuccess) return LD_ERR_HIP;   // (a caller's scratch: not known to be zero)
-            int st = tables ? groupnorm_scale_shift_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, HW, (const half_t*)gamma, (const half_t*)beta, eps, part, scale, shift, stream)
-                            : groupnorm_stats_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, HW, part, stream);
-            if (tables) c8.gn_in_part = nullptr;
-            if (st == LD_OK) st = conv8_repack_launch((const half_t*)wt, cout, C, w8, stream);   // (per call here; the UNet executor keeps the copy resident)
-            if (st != LD_OK) return st;
-            return gemm_launch(c8, stream);
-        }
-    }
     if (gemm_conv_fuses_groupnorm(p)) {
         int st = groupnorm_scale_shift_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, HW, (const half_t*)gamma, (const half_t*)beta, eps, part,
                                               scale, shift, stream);
@@ -169,6 +149,12 @@ int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, 
     int st = groupnorm_launch((const half_t*)x1, c1, (const half_t*)x2, c2, n, HW, (const half_t*)gamma, (const half_t*)beta, eps, 1, g, part, stream);
     if (st != LD_OK) return st;
     p.A = g; p.A2 = nullptr; p.C1 = C; p.C2 = 0;
+    p.sync = sync; p.W8 = w8;
+    if (conv8_plan(p, nullptr)) {   // row-resident kernel (conv8.hip) on the normalised tensor: zeroed counters and its own weight layout
+        if (hipMemsetAsync(sync, 0, LD_SYNC_INTS * sizeof(int), stream) != hipSuccess) return LD_ERR_HIP;   // (a caller's scratch: not known to be zero)
+        st = conv8_repack_launch((const half_t*)wt, cout, C, w8, stream);   // (per call here; the UNet executor keeps the copy resident)
+        if (st != LD_OK) return st;
+    }
     return gemm_launch(p, stream);
 }
 

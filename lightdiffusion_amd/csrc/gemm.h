@@ -39,6 +39,7 @@ struct GemmParams {
     int bm = 0, bn = 0;          // bn must match the repack-time choice for GEGLU
     int splitk = 0;
     int m_fastest = -1;          // tile order: -1 auto, 0 n fastest, 1 m fastest
+    int xcd_gm = 0;              // (internal, 256 x 320 plain GEMM) XCD-blocked tile order: XCDs split gm x (8 / gm) over (M, N); 0 = off
     float* partial = nullptr;    // split-K workspace, >= splitk*M*N floats
     size_t partial_bytes = 0;
     // ---- LayerNorm folded into the contractions around it (v3 / v4 kernels, no split-K; unet.hip "ln fold"):
@@ -66,13 +67,7 @@ struct GemmParams {
     float* gn_part = nullptr;          // [n_img][gn_P][32][2] floats
     int gn_P = 0, gn_ppb = 0, gn_HW = 0;
     int* gn_part_done = nullptr;       // host int, set to the number of pixel chunks per image of the partials that were written (0: none)
-    // ---- row-resident small-M convolution (conv8.hip): GroupNorm(+SiLU) of the INPUT applied while the activations are staged, with
-    //   scale / shift finished IN the kernel from partial statistics [n_img][gn_in_P][32][2] (gn_stats_kernel's layout, any chunk count)
-    const float* gn_in_part = nullptr;
-    int gn_in_P = 0;
-    const half_t* gn_gamma = nullptr;
-    const half_t* gn_beta = nullptr;
-    float gn_eps = 0.f;
+    // ---- row-resident small-M convolution (conv8.hip)
     const half_t* W8 = nullptr;  // the weights in conv8's own layout (conv8_repack_launch): required for that kernel
     //   its in-launch reduction of the channel-slab partial sums needs >= 4 * (N / 80) zeroed ints that it leaves zeroed (self-resetting)
     int* sync = nullptr;

@@ -1264,7 +1264,17 @@ __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
     int bid = xcd_remap(blockIdx.x, tiles * splitk);
     const int ks = bid / tiles;
     bid -= ks * tiles;
-    const int tn_i = bid % tiles_n, tm_i = bid / tiles_n;
+    int tn_i = bid % tiles_n, tm_i = bid / tiles_n;
+    if (!CONV && p.xcd_gm > 0) {
+        // plain GEMM, XCD-blocked tile order: XCD x (a contiguous run of tiles / 8 logical ids) owns the block (x / gn, x % gn) of a gm x gn grid
+        // over the tile matrix and walks it M-fastest — the workgroups that run together on one XCD share a few W tiles and A panels through
+        // its L2.  (N-fastest over whole M panels made every XCD stream ALL of W once per M panel: 433 MB fetched per launch for the
+        // 26 MB matrix of the level-2 GEGLU, profiles/pmc_traffic.json round 3.)
+        const int gn = 8 / p.xcd_gm, per = tiles >> 3, x = bid / per, l = bid - x * per;
+        const int bm_t = tiles_m / p.xcd_gm, bn_t = tiles_n / gn;
+        tm_i = (x / gn) * bm_t + l % bm_t;
+        tn_i = (x % gn) * bn_t + l / bm_t;
+    }
 #ifdef LD_AB_BUILD
     const int m0 = (p.dbg & 64) ? 0 : tm_i * V5_BM, n0 = (p.dbg & 64) ? 0 : tn_i * V5_BN;
 #else
@@ -2453,16 +2463,12 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     if (p.n_valid <= 0 || p.n_valid > p.N) p.n_valid = p.N;
     // ---- conv8 (row-resident, weights streamed once, in-launch slab reduction): the two-image 16x16 / 8x8 levels of a batch-1 step
     if (conv8_plan(p, nullptr)) {
-        const bool up8 = p.Hv == 2 * p.Hs, gn8 = p.gn_in_part != nullptr || p.gn_scale != nullptr;
-        static const char* names[4][3] = {{"conv8_kernel<W8>", "conv8_kernel<W8,groupnorm>", "conv8_kernel<W8,up>"},
-                                          {"conv8_kernel<W16>", "conv8_kernel<W16,groupnorm>", "conv8_kernel<W16,up>"},
-                                          {"conv8_kernel<W32>", "conv8_kernel<W32,groupnorm>", "conv8_kernel<W32,up>"},
-                                          {"conv8_kernel<W64>", "conv8_kernel<W64,groupnorm>", "conv8_kernel<W64,up>"}};
-        t_last_kernel = names[p.Wo == 8 ? 0 : p.Wo == 16 ? 1 : p.Wo == 32 ? 2 : 3][up8 ? 2 : gn8 ? 1 : 0];
+        static const char* names[4][2] = {{"conv8_kernel<W8>", "conv8_kernel<W8,up>"}, {"conv8_kernel<W16>", "conv8_kernel<W16,up>"},
+                                          {"conv8_kernel<W32>", "conv8_kernel<W32,up>"}, {"conv8_kernel<W64>", "conv8_kernel<W64,up>"}};
+        t_last_kernel = names[p.Wo == 8 ? 0 : p.Wo == 16 ? 1 : p.Wo == 32 ? 2 : 3][p.Hv == 2 * p.Hs ? 1 : 0];
         if (p.gn_part != nullptr && p.gn_part_done != nullptr) *p.gn_part_done = conv8_gn_chunks(p);
         return conv8_launch(p, stream);
     }
-    if (p.gn_in_part != nullptr) return LD_ERR_ARG;   // only conv8 finishes a GroupNorm from partial statistics (ask conv8_plan first)
     // ---- v6 (halo-tile 3x3 convolution on the v5 skeleton): stride-1 convs whose tiles are whole image rows and fill the chip
     V6Plan pl;
     if (v6_plan(p, &pl)) {
@@ -2574,6 +2580,26 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
                     hipLaunchKernelGGL((gemm5_kernel<true, 0>), grid, dim3(512), 0, stream, p);
                 } else {
                     t_last_kernel = "gemm5_kernel<256,320,plain>";
+                    {   // XCD-blocked tile order (see the kernel): the split of the 8 XCDs over (M, N) that moves the fewest bytes, A once per
+                        // N group and W once per M group
+                        const int tm5 = (p.M + V5_BM - 1) / V5_BM, tn5 = p.N / V5_BN;
+                        p.xcd_gm = 0;
+                        if (p.batch == 1 && (tm5 * tn5) % 8 == 0 && p.M % V5_BM == 0) {
+                            double best = 0;
+                            for (int gm = 1; gm <= 8; gm <<= 1) {
+                                const int gn = 8 / gm;
+                                if (tm5 % gm || tn5 % gn) continue;
+                                const double cost = (double)p.M * gn + (double)p.N * gm;     // x K x 2 bytes
+                                if (p.xcd_gm == 0 || cost < best) {
+                                    best = cost;
+                                    p.xcd_gm = gm;
+                                }
+                            }
+                        }
+#ifdef LD_AB_BUILD
+                        if (g_no_v5 & 512) p.xcd_gm = 0;
+#endif
+                    }
                     if (p.act == 2) hipLaunchKernelGGL((gemm5_kernel<false, 2>), grid, dim3(512), 0, stream, p);
                     else if (ln) hipLaunchKernelGGL((gemm5_kernel<false, 1>), grid, dim3(512), 0, stream, p);
                     else hipLaunchKernelGGL((gemm5_kernel<false, 0>), grid, dim3(512), 0, stream, p);

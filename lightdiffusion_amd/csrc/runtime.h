@@ -186,6 +186,7 @@ struct Exec {
     double flops = 0.0;
     float* splitk_ws = nullptr;
     size_t splitk_bytes = 0;
+    int ab_flags = 0;                // A/B build only (ld_debug_unet_flags): 4 = row-resident convolution (conv8.hip) off
     int* sync_ws = nullptr;          // LD_SYNC_INTS zeroed ints for the in-launch reductions (gemm.h GemmParams::sync); null: those kernels are not used
 
     void note(int st) {
@@ -224,6 +225,7 @@ struct Exec {
             p.partial_bytes = splitk_bytes;
             p.sync = sync_ws;
         }
+        if (ab_flags & 4) p.W8 = nullptr;
         launches += 1;
         if (dry || status != LD_OK) return;
         t_begin(p.conv && p.ksize == 3 ? KC_CONV3 : KC_GEMM, fl, 1, p.conv ? (p.ksize == 3 ? "conv3" : "conv1") : (p.act == 2 ? "geglu" : "gemm"),
@@ -255,46 +257,7 @@ struct Exec {
         p.partial_bytes = splitk_bytes;
         p.sync = sync_ws;
         if (ready_P <= 0) ready = nullptr;
-        {   // row-resident kernel (conv8.hip): the normalisation is applied inside the convolution — finished there from partial statistics, or
-            // (a slab that touches many groups: the 64 x 64 level) from scale / shift finished by gn_finalize_kernel
-            GemmParams q = p;
-            q.gn_in_part = ready != nullptr ? ready : reinterpret_cast<const float*>(p.A);   // (placeholder for the plan: any non-null pointer)
-            q.gn_in_P = ready != nullptr ? ready_P : gn_num_chunks(n_img, HW);
-            q.gn_gamma = gamma; q.gn_beta = beta; q.gn_eps = eps; q.gn_silu = 1;
-            bool direct = conv8_plan(q, nullptr), tables = false;
-            if (!direct) {
-                q.gn_scale = reinterpret_cast<const float*>(p.A);   // (placeholder)
-                q.gn_shift = q.gn_scale;
-                tables = conv8_plan(q, nullptr);
-            }
-            if (direct || tables) {
-                const size_t m = arena->mark();
-                const int C = p.C1 + p.C2;
-                float* ws = ready != nullptr ? ready : reinterpret_cast<float*>(arena->alloc(groupnorm_workspace_bytes(n_img, HW)));
-                if (tables) {
-                    float* scale = reinterpret_cast<float*>(arena->alloc((size_t)n_img * C * sizeof(float)));
-                    float* shift = reinterpret_cast<float*>(arena->alloc((size_t)n_img * C * sizeof(float)));
-                    const int nl = ready != nullptr ? 1 : 2;
-                    launches += nl;
-                    t_begin(KC_GNORM, 0.0, nl, "gn_stats", n_img, HW, C, 1);
-                    if (!dry && status == LD_OK)
-                        note(groupnorm_scale_shift_launch(p.A, p.C1, p.A2, p.C2, n_img, HW, gamma, beta, eps, ws, scale, shift, stream, ready != nullptr ? ready_P : 0));
-                    t_end(ready != nullptr ? "gn_finalize_kernel" : "gn_stats_kernel+gn_finalize_kernel");
-                    q.gn_scale = scale;
-                    q.gn_shift = shift;
-                    q.gn_in_part = nullptr;
-                } else if (ready == nullptr) {
-                    launches += 1;
-                    t_begin(KC_GNORM, 0.0, 1, "gn_stats", n_img, HW, C, 1);
-                    if (!dry && status == LD_OK) note(groupnorm_stats_launch(p.A, p.C1, p.A2, p.C2, n_img, HW, ws, stream));
-                    t_end("gn_stats_kernel");
-                    q.gn_in_part = ws;
-                }
-                gemm(q);
-                arena->release(m);
-                return;
-            }
-        }
+        if (ab_flags & 4) p.W8 = nullptr;
         if (gemm_conv_fuses_groupnorm(p)) {
             const int C = p.C1 + p.C2;
             const size_t m = arena->mark();

@@ -475,19 +475,12 @@ struct Run {
             a.scale = 1.0f / sqrtf((float)d);
             ex.attention(a);
         }
-        if (pair_pending) {
-            // CFG pair: everything up to here saw the same input in both halves of the batch and ran on the first half only.  The cross-attention
-            // below is the first operation that reads the conditioning: copy the residual stream t, the self-attention output and the block's
-            // input (its residual at the end) into the second half and carry on with all n_alloc samples.  (The out-projection of attn1 runs on
-            // both halves: its LayerNorm-fold statistics are laid out by the row count of the GEMM that writes them.)
-            const size_t hb = (size_t)M * C * sizeof(half_t);
-            dup(t, hb);
-            dup(ao, hb);
-            dup(const_cast<half_t*>(x), hb);
-            pair_pending = false;
-            n = n_alloc;
-            M = n * L;
-        }
+        // CFG pair: everything up to the cross-attention's K / V sees the same input in both halves of the batch and runs on the first half only
+        // — also the out-projection of attn1, the LayerNorm-2 statistics it emits and the q projection of attn2 (only K / V of attn2 read the
+        // conditioning).  Then the residual stream t, q2 and the block's input (its residual at the end) are copied into the second half and
+        // everything else runs on all n_alloc samples (the statistics of the first half are not needed again: the out-projection of attn2
+        // rewrites them for all rows).
+        const bool split_here = pair_pending;
         producer(ao, C, s.o1_w, s.o1_b, t, C);
         // ---- cross attention against the hoisted context K / V^T
         if (!fold) ex.layernorm(t, P(s.ln2_g), P(s.ln2_b), nrm, M, C);
@@ -503,6 +496,15 @@ struct Run {
                 ln_args(p, s.f_q2_s);
             }
             ex.gemm(p);
+        }
+        if (split_here) {
+            const size_t hb = (size_t)M * C * sizeof(half_t);
+            dup(t, hb);
+            dup(q2, hb);
+            dup(const_cast<half_t*>(x), hb);
+            pair_pending = false;
+            n = n_alloc;
+            M = n * L;
         }
         {
             const int Tp = u->ctx_tpad;
@@ -614,6 +616,9 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
     ex.splitk_ws = u->splitk_ws;
     ex.splitk_bytes = u->splitk_bytes;
     ex.sync_ws = u->sync_ws;
+#ifdef LD_AB_BUILD
+    ex.ab_flags = g_unet_dbg;
+#endif
     if (u->want_timing && !dry) {
         u->timing.reset();
         ex.timing = &u->timing;

@@ -1,6 +1,7 @@
-"""GPU parity of the row-resident convolution (csrc/conv8.hip) — the two-image 16x16 / 8x8 levels of a batch-1 step: ResBlock1's
-GroupNorm + SiLU + conv3x3 (+ time-embedding row + skip, LD.py:5224-5287) and Upsample1's nearest-2x + conv (LD.py:5141-5152), called
-through the C ABI (ld_op_groupnorm_conv / ld_op_conv) against a torch fp32 evaluation of the same op on the same fp16-rounded inputs.
+"""GPU parity of the row-resident convolution (csrc/conv8.hip) — the two-image (CFG pair) levels of a batch-1 step: ResBlock1's
+GroupNorm + SiLU (norm.hip) + conv3x3 (+ time-embedding row + skip, LD.py:5224-5287) and Upsample1's nearest-2x + conv (LD.py:5141-5152),
+called through the C ABI (ld_op_groupnorm_conv / ld_op_conv) against a torch fp32 evaluation of the same op on the same fp16-rounded
+inputs.  Cases with more than two images take the general kernels through the same entry points (conv8_plan declines them).
 Tolerance: rel-L2 <= 2e-3 (fp16 storage, fp32 accumulate; the channel-slab partial sums are fp32 and summed in a fixed order)."""
 import math
 
@@ -39,8 +40,7 @@ def nchw(x):
 # (h = w, c1, c2, cout, time-embedding row, residual): every ResBlock convolution of SD1.5's 16x16 / 8x8 levels and the middle block at
 # UNet batch 2 — in_layers of the down path (640 -> 1280, 1280 -> 1280), of the up path (concat 1280 + 1280 / 1280 + 640: groups of 80 / 60
 # channels, the second one straddling the 16-channel sub-slabs AND the source boundary), out_layers (residual = skip)
-# and the 32x32 / 64x64 levels (patches of four / two image rows; at 64x64 one workgroup sweeps all of K and the scale / shift tables come from
-# gn_finalize_kernel), plus the 8x8 level at UNet batch 16 (eight two-image patches)
+# and the 32x32 / 64x64 levels (patches of four / two image rows; at 64x64 one workgroup sweeps all of K), plus batch 16 / 4 / 1 cases
 @pytest.mark.parametrize("n,hw,c1,c2,cout,rv,res", [
     (2, 16, 1280, 0, 1280, True, False), (2, 16, 1280, 0, 1280, False, True), (2, 16, 640, 0, 1280, True, False),
     (2, 16, 1280, 1280, 1280, True, False), (2, 16, 1280, 640, 1280, True, True),
@@ -82,7 +82,8 @@ def test_groupnorm_silu_conv_row_resident(ops, n, hw, c1, c2, cout, rv, res):
     (2, 64, 640, 640, True, False, False),       # ... of the 32x32 level
     (2, 16, 1280, 1280, False, True, True),      # plain (no GroupNorm) route
     (2, 8, 1280, 1280, False, False, True),
-    (2, 64, 320, 320, False, True, False)])
+    (2, 64, 320, 320, False, True, False),
+    (2, 32, 640, 640, False, True, True)])       # 128 (patch, N tile) counters of the in-launch reduction
 def test_conv_row_resident(ops, n, hw, cin, cout, up, rv, res):
     hs = hw // 2 if up else hw
     x = r16((n, cin, hs, hs), 211)
