@@ -149,6 +149,11 @@ int ld_op_layernorm(const void* x, const void* gamma, const void* beta, void* y,
  * causal != 0 masks keys after the query position (the CLIP text model's mask, LD.py:4440-4446) */
 int ld_op_attention(const void* q, int ldq, const void* k, int ldk, const void* vt, int ldvt, void* o, int ldo, int b,
                     int heads, int lq, int lk, int d, float scale, int causal, void* stream);
+/* the same with V row-major, v [b][lk][ldv] like k — the form the UNet executor runs on the output of its fused q|k|v projection
+ * (q, k, v may be column blocks of one [b][l][3*heads*d] tensor: ldq = ldk = ldv = 3*heads*d; requires lq == lk then for the batch strides);
+ * the kernel transposes V while it reads it from LDS (ds_read_b64_tr_b16) */
+int ld_op_attention_rowv(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int b,
+                         int heads, int lq, int lk, int d, float scale, int causal, void* stream);
 int ld_op_softmax_rows(void* s, int rows, int cols, void* stream);
 int ld_op_timestep_embed(const float* sigma, const float* log_sigmas, int n_sigmas, int n, int dim, void* out_f16, float* t_out,
                          void* stream);

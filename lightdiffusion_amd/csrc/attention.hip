@@ -39,8 +39,13 @@ constexpr int AT_THREADS = 256;
 
 __device__ uint4 g_att_zero[8];                                                     // 128 zero bytes
 __device__ uint4 g_att_ones = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};   // 8 x fp16 1.0
+__device__ uint4 g_att_one_last = {0u, 0u, 0u, 0x3C000000u};                          // 7 x 0, then fp16 1.0 (the "ones" column of a row-major V tile)
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
-template <int DK, bool MASKED, int NW, int WPS>   // NW waves = 32*NW queries per workgroup share each K / V^T tile
+// VROW: V arrives row-major ([key][channel], e.g. the third block of a fused q|k|v projection) and the V^T fragments are read through
+// ds_read_b64_tr_b16 (two transposing 8-byte reads per fragment instead of one 16-byte read); otherwise V^T [channel][key].
+template <int DK, bool MASKED, int NW, int WPS, bool VROW>   // NW waves = 32*NW queries per workgroup share each K / V tile
 __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnParams p) {
     constexpr int DV = (DK + 1) / 2;
     constexpr bool ONES = (DK & 1) != 0;
@@ -64,9 +69,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
 
     const half_t* Qg = p.Q + (long long)b * p.sQ + head * d;
     const half_t* Kg = p.K + (long long)b * p.sK + head * d;
-    const half_t* Vg = p.Vt + (long long)b * p.sV + (long long)head * d * p.ldvt;
+    const half_t* Vg = VROW ? p.V + (long long)b * p.sV + head * d : p.Vt + (long long)b * p.sV + (long long)head * d * p.ldvt;
     const half_t* zp = reinterpret_cast<const half_t*>(g_att_zero);
-    const half_t* op = reinterpret_cast<const half_t*>(&g_att_ones);
+    const half_t* op = reinterpret_cast<const half_t*>(VROW ? &g_att_one_last : &g_att_ones);
 
     const int qrow = qb * (32 * NW) + wid * 32 + r;
     // Q is folded with scale*log2(e) once, so QK^T comes out of the matrix core already in the exp2 domain
@@ -104,10 +109,21 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
         krow[i] = key;
         kval[i] = row < KT;
         kp[i] = kval[i] ? Kg + (long long)key * p.ldk + ((cph ^ ((row >> sw_shift) & sw_mask)) << 3) : zp;
-        const int vr = q >> 3, vc = (q & 7) ^ (vr & 7);
-        vkey[i] = vc << 3;
-        vdat[i] = vr < d;
-        vp[i] = vdat[i] ? Vg + (long long)vr * p.ldvt + (vc << 3) : ((ONES && vr == 32 * DV - 1) ? op : zp);
+        if (VROW) {
+            // row-major V tile: 64 key rows of 4*DV 16-byte chunks (32*DV channels: d data channels, zeros, and with ONES a last
+            // column of 1.0 whose O^T row is the softmax denominator); the 64-byte groups of a row are XORed with row bits so that the
+            // four rows a transposing read gathers (64 bytes each, per 32-lane half) fall into four different quarters of the 256-byte bank line
+            const int vr = q / (4 * DV), pc = q - vr * (4 * DV);
+            const int vc = pc ^ ((DV == 2 ? ((vr >> 1) & 1) : DV == 4 ? (vr & 3) : 0) << 2);
+            vkey[i] = vr;
+            vdat[i] = vr < KT && vc < dch;
+            vp[i] = vdat[i] ? Vg + (long long)vr * p.ldv + (vc << 3) : ((ONES && vr < KT && vc == 4 * DV - 1) ? op : zp);
+        } else {
+            const int vr = q >> 3, vc = (q & 7) ^ (vr & 7);
+            vkey[i] = vc << 3;
+            vdat[i] = vr < d;
+            vp[i] = vdat[i] ? Vg + (long long)vr * p.ldvt + (vc << 3) : ((ONES && vr == 32 * DV - 1) ? op : zp);
+        }
     }
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     auto issue = [&](int key0, int buf) {
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
 #pragma unroll
         for (int i = 0; i < LIT; ++i) kp[i] += kval[i] ? (long long)KT * p.ldk : 0;
 #pragma unroll
-        for (int i = 0; i < LIT; ++i) vp[i] += vdat[i] ? KT : 0;
+        for (int i = 0; i < LIT; ++i) vp[i] += vdat[i] ? (VROW ? (long long)KT * p.ldv : (long long)KT) : 0;
     };
 
     // ---- fragment read offsets (halfs, relative to the K tile / V^T tile of a buffer)
@@ -144,6 +160,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
     int voff[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) voff[c] = TILE_CH * 8 + ((r * 8 + ((2 * c + hh) ^ (r & 7))) << 3);   // c = 2*sub + k2
+    // VROW: lane (r, hh) = 16-lane group (r >> 4) + 2 hh; lane 4 tq + tp of a group addresses row tq, channels 4 tp .. 4 tp + 3 of its 4 x 16
+    // block and receives channel (r & 15) of the block's 4 rows: keys 8 hh + 4 rd + (0..3) (+ 32 sub + 16 k2), channels 32 tt + 16 (r >> 4) + ...
+    int voffr[DV];
+    {
+        const int tq = (r >> 2) & 3, tp = r & 3, g1 = (r >> 4) & 1;
+        const int sw = DV == 2 ? ((tq >> 1) & 1) : DV == 4 ? tq : 0;
+#pragma unroll
+        for (int tt = 0; tt < DV; ++tt)
+            voffr[tt] = TILE_CH * 8 + (8 * hh + tq) * (32 * DV) + ((tt ^ sw) << 5) + ((2 * g1 + (tp >> 1)) << 3) + 4 * (tp & 1);
+    }
 
     f32x16 o[DV];
 #pragma unroll
@@ -272,7 +298,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
 #elif LD_ATT_DBG == 4
                     const half8 vf = as_half8(ld16(T + voff[2 * sub]));
 #else
-                    const half8 vf = as_half8(ld16(T + tt * 32 * 64 + voff[2 * sub + k2]));
+                    half8 vf;
+                    if (VROW) {
+                        const half_t* vsrc = T + voffr[tt] + (32 * sub + 16 * k2) * (32 * DV);
+                        const half4v lo = __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vsrc)));
+                        const half4v hi = __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vsrc + 4 * (32 * DV))));
+                        vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    } else {
+                        vf = as_half8(ld16(T + tt * 32 * 64 + voff[2 * sub + k2]));
+                    }
 #endif
                     o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[k2], o[tt], 0, 0, 0);
                 }
@@ -321,7 +355,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
 
 thread_local const char* t_last_attn_kernel = "";
 
-template <int DK>
+template <int DK, bool VROW>
 void launch_attn(const AttnParams& p, hipStream_t s) {
     const int nblk = ((p.Lq + 127) / 128) * p.H * p.B;
     // min waves per SIMD handed to __launch_bounds__: with it hipcc keeps the MFMA accumulators in VGPRs (no v_accvgpr
@@ -333,16 +367,16 @@ void launch_attn(const AttnParams& p, hipStream_t s) {
     const long long nblk8 = (long long)((p.Lq + 255) / 256) * p.H * p.B;
     // measured (tools/attn_micro.py): d=40 L=4096 -1.6 %, L=16384 -5 %; d=80 L=1024 +1 % (142 VGPRs: one workgroup per CU)
     const bool big = DK <= 4 && p.Lq >= 2048 && nblk8 >= 512;
-    static const std::string names[4] = {"flash_attn2_kernel<" + std::to_string(DK) + ",plain,4>", "flash_attn2_kernel<" + std::to_string(DK) + ",masked,4>",
-                                         "flash_attn2_kernel<" + std::to_string(DK) + ",plain,8>", "flash_attn2_kernel<" + std::to_string(DK) + ",masked,8>"};
+    static const std::string pre = "flash_attn2_kernel<" + std::to_string(DK) + (VROW ? ",rowV" : "");
+    static const std::string names[4] = {pre + ",plain,4>", pre + ",masked,4>", pre + ",plain,8>", pre + ",masked,8>"};
     t_last_attn_kernel = names[(big ? 2 : 0) + (masked ? 1 : 0)].c_str();
     if (big) {
         constexpr int W8 = DK <= 4 ? 4 : 2;   // waves per SIMD the register budget is cut for (two or one workgroup per CU)
-        if (masked) hipLaunchKernelGGL((flash_attn2_kernel<DK, true, 8, W8>), dim3((unsigned)nblk8), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((flash_attn2_kernel<DK, false, 8, W8>), dim3((unsigned)nblk8), dim3(512), 0, s, p);
+        if (masked) hipLaunchKernelGGL((flash_attn2_kernel<DK, true, 8, W8, VROW>), dim3((unsigned)nblk8), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((flash_attn2_kernel<DK, false, 8, W8, VROW>), dim3((unsigned)nblk8), dim3(512), 0, s, p);
     } else {
-        if (masked) hipLaunchKernelGGL((flash_attn2_kernel<DK, true, 4, AUTO_WPS>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
-        else hipLaunchKernelGGL((flash_attn2_kernel<DK, false, 4, AUTO_WPS>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
+        if (masked) hipLaunchKernelGGL((flash_attn2_kernel<DK, true, 4, AUTO_WPS, VROW>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((flash_attn2_kernel<DK, false, 4, AUTO_WPS, VROW>), dim3(nblk), dim3(AT_THREADS), 0, s, p);
     }
 }
 
@@ -351,23 +385,38 @@ void launch_attn(const AttnParams& p, hipStream_t s) {
 const char* attention_last_kernel_name() { return t_last_attn_kernel; }
 
 int attention_launch(const AttnParams& p, hipStream_t stream) {
-    if (p.Q == nullptr || p.K == nullptr || p.Vt == nullptr || p.O == nullptr) return LD_ERR_ARG;
+    if (p.Q == nullptr || p.K == nullptr || (p.Vt == nullptr) == (p.V == nullptr) || p.O == nullptr) return LD_ERR_ARG;   // exactly one of V^T / V
     if (p.B <= 0 || p.H <= 0 || p.Lq <= 0 || p.Lk <= 0) return LD_ERR_SHAPE;
     if (p.d % 8 || p.d <= 0 || p.d > 160) return LD_ERR_SHAPE;
     // 16-byte row copies: every row start must be 16-byte aligned; V^T rows are read in 8-key chunks, so the
     // V^T buffer must be allocated (and zero-padded) to a multiple of 8 keys per row
-    if ((p.ldq & 7) || (p.ldk & 7) || (p.ldvt & 7) || (p.ldo & 3) || (p.sQ & 7) || (p.sK & 7) || (p.sV & 7)) return LD_ERR_SHAPE;
-    if (p.ldvt < ((p.Lk + 7) & ~7)) return LD_ERR_SHAPE;
+    if ((p.ldq & 7) || (p.ldk & 7) || (p.ldo & 3) || (p.sQ & 7) || (p.sK & 7) || (p.sV & 7)) return LD_ERR_SHAPE;
     const int dk = (p.d + 15) / 16;
+    if (p.V != nullptr) {   // row-major V (the UNet's fused q|k|v projection)
+        if ((p.ldv & 7) || p.ldv < p.d) return LD_ERR_SHAPE;
+        switch (dk) {
+            case 1: launch_attn<1, true>(p, stream); break;
+            case 2: launch_attn<2, true>(p, stream); break;
+            case 3: launch_attn<3, true>(p, stream); break;
+            case 4: launch_attn<4, true>(p, stream); break;
+            case 5: launch_attn<5, true>(p, stream); break;
+            case 6: launch_attn<6, true>(p, stream); break;
+            case 8: launch_attn<8, true>(p, stream); break;
+            case 10: launch_attn<10, true>(p, stream); break;
+            default: return LD_ERR_SHAPE;
+        }
+        return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+    }
+    if ((p.ldvt & 7) || p.ldvt < ((p.Lk + 7) & ~7)) return LD_ERR_SHAPE;
     switch (dk) {
-        case 1: launch_attn<1>(p, stream); break;
-        case 2: launch_attn<2>(p, stream); break;
-        case 3: launch_attn<3>(p, stream); break;
-        case 4: launch_attn<4>(p, stream); break;
-        case 5: launch_attn<5>(p, stream); break;
-        case 6: launch_attn<6>(p, stream); break;
-        case 8: launch_attn<8>(p, stream); break;
-        case 10: launch_attn<10>(p, stream); break;
+        case 1: launch_attn<1, false>(p, stream); break;
+        case 2: launch_attn<2, false>(p, stream); break;
+        case 3: launch_attn<3, false>(p, stream); break;
+        case 4: launch_attn<4, false>(p, stream); break;
+        case 5: launch_attn<5, false>(p, stream); break;
+        case 6: launch_attn<6, false>(p, stream); break;
+        case 8: launch_attn<8, false>(p, stream); break;
+        case 10: launch_attn<10, false>(p, stream); break;
         default: return LD_ERR_SHAPE;
     }
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;

@@ -185,6 +185,17 @@ int ld_op_attention(const void* q, int ldq, const void* k, int ldk, const void* 
     return attention_launch(a, (hipStream_t)stream);
 }
 
+int ld_op_attention_rowv(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int b, int heads,
+                         int lq, int lk, int d, float scale, int causal, void* stream) {
+    AttnParams a;
+    a.Q = (const half_t*)q; a.ldq = ldq; a.sQ = (long long)lq * ldq;
+    a.K = (const half_t*)k; a.ldk = ldk; a.sK = (long long)lk * ldk;
+    a.V = (const half_t*)v; a.ldv = ldv; a.sV = (long long)lk * ldv;
+    a.O = (half_t*)o; a.ldo = ldo; a.sO = (long long)lq * ldo;
+    a.B = b; a.H = heads; a.Lq = lq; a.Lk = lk; a.d = d; a.scale = scale; a.causal = causal;
+    return attention_launch(a, (hipStream_t)stream);
+}
+
 int ld_op_softmax_rows(void* s, int rows, int cols, void* stream) {
     return softmax_rows_launch((half_t*)s, rows, cols, cols, (hipStream_t)stream);
 }

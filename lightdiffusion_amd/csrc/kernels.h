@@ -37,6 +37,8 @@ struct AttnParams {
     const half_t* Q = nullptr;   // element (b, l, h, dd) at Q + b*sQ + l*ldq + h*d + dd
     const half_t* K = nullptr;   // element (b, key, h, dd) at K + b*sK + key*ldk + h*d + dd
     const half_t* Vt = nullptr;  // element (b, h, dd, key) at Vt + b*sV + (h*d + dd)*ldvt + key   (V transposed)
+    const half_t* V = nullptr;   // ... or row-major: element (b, key, h, dd) at V + b*sV + key*ldv + h*d + dd  (exactly one of Vt / V)
+    int ldv = 0;
     half_t* O = nullptr;         // element (b, l, h, dd) at O + b*sO + l*ldo + h*d + dd
     int ldq = 0, ldk = 0, ldvt = 0, ldo = 0;
     long long sQ = 0, sK = 0, sV = 0, sO = 0;

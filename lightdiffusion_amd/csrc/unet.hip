@@ -25,7 +25,7 @@ struct StW {
     int c = 0, bn = 0, ctx_slot = 0;
     // LN fold (derived at the first forward after a weight load): gamma-folded weights / beta-folded biases (byte offsets into
     // ld_unet::fold_base) and their fp32 row sums, for the projections that consume LN1 (q|k, v), LN2 (q of attn2), LN3 (GEGLU)
-    size_t f_qk_w = 0, f_v_w = 0, f_q2_w = 0, f_ff1_w = 0, f_qk_b = 0, f_v_b = 0, f_q2_b = 0, f_ff1_b = 0, f_qk_s = 0, f_v_s = 0, f_q2_s = 0,
+    size_t f_qk_w = 0, f_q2_w = 0, f_ff1_w = 0, f_qk_b = 0, f_q2_b = 0, f_ff1_b = 0, f_qk_s = 0, f_q2_s = 0,
            f_ff1_s = 0;
     // MLP-out fold: [Wpo W2 | Wpo] ([C][5C]) and Wpo b2 + bpo — ff.net.2 and proj_out run as ONE two-source contraction
     size_t f_mo_w = 0, f_mo_b = 0;
@@ -146,7 +146,7 @@ int add_st(ld_unet* u, const std::string& p, int c) {
     s.ln1_b = t.add(b + ".norm1.bias", PK_VEC, {c});
     s.q1_w = t.add(b + ".attn1.to_q.weight", PK_MAT, {c, c});
     s.k1_w = t.add(b + ".attn1.to_k.weight", PK_MAT, {c, c}, 16);   // contiguous with to_q: one [2C][C] projection
-    s.v1_w = t.add(b + ".attn1.to_v.weight", PK_MAT, {c, c});
+    s.v1_w = t.add(b + ".attn1.to_v.weight", PK_MAT, {c, c}, 16);   // ... and to_v: one [3C][C] projection (the attention kernel reads V row-major)
     s.o1_w = t.add(b + ".attn1.to_out.0.weight", PK_MAT, {c, c});
     s.o1_b = t.add(b + ".attn1.to_out.0.bias", PK_VEC, {c});
     s.ln2_g = t.add(b + ".norm2.weight", PK_VEC, {c});
@@ -172,16 +172,13 @@ int add_st(ld_unet* u, const std::string& p, int c) {
             return o;
         };
         const size_t C = (size_t)c;
-        s.f_qk_w = take(2 * C * C * sizeof(half_t));
-        s.f_v_w = take(C * C * sizeof(half_t));
+        s.f_qk_w = take(3 * C * C * sizeof(half_t));   // [Wq ; Wk ; Wv] of attn1
         s.f_q2_w = take(C * C * sizeof(half_t));
         s.f_ff1_w = take(8 * C * C * sizeof(half_t));
-        s.f_qk_b = take(2 * C * sizeof(half_t));
-        s.f_v_b = take(C * sizeof(half_t));
+        s.f_qk_b = take(3 * C * sizeof(half_t));
         s.f_q2_b = take(C * sizeof(half_t));
         s.f_ff1_b = take(8 * C * sizeof(half_t));
-        s.f_qk_s = take(2 * C * sizeof(float));
-        s.f_v_s = take(C * sizeof(float));
+        s.f_qk_s = take(3 * C * sizeof(float));
         s.f_q2_s = take(C * sizeof(float));
         s.f_ff1_s = take(8 * C * sizeof(float));
         s.f_mo_w = take(5 * C * C * sizeof(half_t));
@@ -404,10 +401,8 @@ struct Run {
         half_t* g = ar.halfs(Ma * C);
         ex.groupnorm(x, C, nullptr, 0, n, L, P(s.gn_g), P(s.gn_b), 1e-6f, 0, g, in_stats, in_P);
         half_t* t = ar.halfs(Ma * C);
-        const int Lp = (L + 7) & ~7;   // V^T rows are padded to 8 keys (16-byte row copies in the attention kernel)
         half_t* nrm = g;               // reuse (only the un-folded path materialises LN(x))
-        half_t* qk = ar.halfs(Ma * 2 * C);
-        half_t* vt = ar.halfs((size_t)na() * C * Lp);
+        half_t* qkv = ar.halfs(Ma * 3 * C);
         half_t* ao = ar.halfs(Ma * C);
         half_t* ff = nullptr;
         const bool fold = u->ln_fold;
@@ -439,37 +434,24 @@ struct Run {
         producer(g, C, s.pin_w, s.pin_b, nullptr, C);
         // ---- self attention: x += to_out(attn(LN1(x)))
         if (!fold) ex.layernorm(t, P(s.ln1_g), P(s.ln1_b), nrm, M, C);
-        {   // [q | k] = LN1(t) [Wq ; Wk]^T
+        {   // [q | k | v] = LN1(t) [Wq ; Wk ; Wv]^T — one launch; the attention kernel reads V row-major (transposing LDS reads), so there
+            // is no V^T projection
             GemmParams p;
             p.A = fold ? t : nrm; p.lda = C;
             p.W = fold ? reinterpret_cast<const half_t*>(fb + s.f_qk_w) : P(s.q1_w); p.ldw = C;
-            p.M = M; p.N = 2 * C; p.K = C;
-            p.C = qk; p.ldc = 2 * C;
+            p.M = M; p.N = 3 * C; p.K = C;
+            p.C = qkv; p.ldc = 3 * C;
             if (fold) {
                 p.bias_n = reinterpret_cast<const half_t*>(fb + s.f_qk_b);
                 ln_args(p, s.f_qk_s);
             }
             ex.gemm(p);
         }
-        {   // V^T[b] = Wv · LN1(t)_b^T  -> [C][Lp] per sample (swapped GEMM: the weight is the row operand)
-            GemmParams p;
-            p.A = fold ? reinterpret_cast<const half_t*>(fb + s.f_v_w) : P(s.v1_w); p.lda = C; p.sA = 0;
-            p.W = fold ? t : nrm; p.ldw = C; p.sW = (long long)L * C;
-            p.M = C; p.N = Lp; p.n_valid = L; p.K = C; p.batch = n;
-            p.C = vt; p.ldc = Lp; p.sC = (long long)C * Lp;
-            if (fold) {
-                p.bias_m = reinterpret_cast<const half_t*>(fb + s.f_v_b);
-                ln_args(p, s.f_v_s);
-                p.ln_swapped = 1;
-                p.ln_zrows = L;
-            }
-            ex.gemm(p);
-        }
         {
             AttnParams a;
-            a.Q = qk; a.ldq = 2 * C; a.sQ = (long long)L * 2 * C;
-            a.K = qk + C; a.ldk = 2 * C; a.sK = (long long)L * 2 * C;
-            a.Vt = vt; a.ldvt = Lp; a.sV = (long long)C * Lp;
+            a.Q = qkv; a.ldq = 3 * C; a.sQ = (long long)L * 3 * C;
+            a.K = qkv + C; a.ldk = 3 * C; a.sK = (long long)L * 3 * C;
+            a.V = qkv + 2 * C; a.ldv = 3 * C; a.sV = (long long)L * 3 * C;
             a.O = ao; a.ldo = C; a.sO = (long long)L * C;
             a.B = n; a.H = heads; a.Lq = L; a.Lk = L; a.d = d;
             a.scale = 1.0f / sqrtf((float)d);
@@ -484,7 +466,7 @@ struct Run {
         producer(ao, C, s.o1_w, s.o1_b, t, C);
         // ---- cross attention against the hoisted context K / V^T
         if (!fold) ex.layernorm(t, P(s.ln2_g), P(s.ln2_b), nrm, M, C);
-        half_t* q2 = qk;   // reuse
+        half_t* q2 = qkv;   // reuse
         {
             GemmParams p;
             p.A = fold ? t : nrm; p.lda = C;
@@ -567,8 +549,7 @@ int fold_layernorms(ld_unet* u, hipStream_t stream) {
         auto H = [&](size_t off) { return reinterpret_cast<half_t*>(fb + off); };
         auto F = [&](size_t off) { return reinterpret_cast<float*>(fb + off); };
         const half_t* P_q1 = u->pt.ptr(s.q1_w);   // to_q and to_k are contiguous: one [2C][C] matrix
-        int st = ln_fold_launch(P_q1, 2 * C, C, u->pt.ptr(s.ln1_g), u->pt.ptr(s.ln1_b), nullptr, H(s.f_qk_w), H(s.f_qk_b), F(s.f_qk_s), stream);
-        if (st == LD_OK) st = ln_fold_launch(u->pt.ptr(s.v1_w), C, C, u->pt.ptr(s.ln1_g), u->pt.ptr(s.ln1_b), nullptr, H(s.f_v_w), H(s.f_v_b), F(s.f_v_s), stream);
+        int st = ln_fold_launch(P_q1, 3 * C, C, u->pt.ptr(s.ln1_g), u->pt.ptr(s.ln1_b), nullptr, H(s.f_qk_w), H(s.f_qk_b), F(s.f_qk_s), stream);
         if (st == LD_OK) st = ln_fold_launch(u->pt.ptr(s.q2_w), C, C, u->pt.ptr(s.ln2_g), u->pt.ptr(s.ln2_b), nullptr, H(s.f_q2_w), H(s.f_q2_b), F(s.f_q2_s), stream);
         if (st == LD_OK) st = ln_fold_launch(u->pt.ptr(s.ff1_w), 8 * C, C, u->pt.ptr(s.ln3_g), u->pt.ptr(s.ln3_b), u->pt.ptr(s.ff1_b), H(s.f_ff1_w), H(s.f_ff1_b), F(s.f_ff1_s), stream);
         if (st == LD_OK) st = mlp_out_fold_launch(u->pt.ptr(s.pout_w), u->pt.ptr(s.ff2_w), u->pt.ptr(s.ff2_b), u->pt.ptr(s.pout_b), C, H(s.f_mo_w), H(s.f_mo_b), stream);

@@ -171,6 +171,30 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, cau
     return o
 
 
+def attention_qkv(qkv: torch.Tensor, heads: int, causal: bool = False) -> torch.Tensor:
+    """Self-attention on a fused projection qkv [b, L, 3*heads*d] = [q | k | v] (how the UNet executor runs attn1 of
+    BasicTransformerBlock, LD.py:4117-4162): V is read row-major, no transposed copy."""
+    b, l, c3 = qkv.shape
+    c = c3 // 3
+    d = c // heads
+    o = torch.empty(b, l, c, dtype=torch.float16, device=qkv.device)
+    base = qkv.data_ptr()
+    check(lib().ld_op_attention_rowv(base, c3, base + 2 * c, c3, base + 4 * c, c3, _p(o), c, b, heads, l, l, d, 1.0 / math.sqrt(d), int(causal),
+                                     _stream()), "ld_op_attention_rowv")
+    return o
+
+
+def attention_rowv(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, causal: bool = False) -> torch.Tensor:
+    """attention() with V handed over row-major [b, Lk, heads*d]."""
+    b, lq, c = q.shape
+    lk = k.shape[1]
+    d = c // heads
+    o = torch.empty_like(q)
+    check(lib().ld_op_attention_rowv(_p(q), c, _p(k.contiguous()), c, _p(v.contiguous()), c, _p(o), c, b, heads, lq, lk, d, 1.0 / math.sqrt(d), int(causal),
+                                     _stream()), "ld_op_attention_rowv")
+    return o
+
+
 def softmax_rows_(s: torch.Tensor) -> torch.Tensor:
     cols = s.shape[-1]
     check(lib().ld_op_softmax_rows(_p(s), s.numel() // cols, cols, _stream()), "ld_op_softmax_rows")

@@ -165,6 +165,30 @@ def test_attention(ops, b, heads, lq, lk, d):
     assert rel_l2(y.float().cpu(), O.attention(q.float(), k.float(), v.float(), heads)) < TOL
 
 
+# V row-major (read through transposing LDS reads): every head dim class (V tile pitches of 64 / 128 / 192 / 256 / 320 bytes, with and without
+# the spare "ones" column), ragged and cross shapes, the 8-wave variant, and the fused [q | k | v] form the UNet executor uses
+@pytest.mark.parametrize("b,heads,lq,lk,d", [
+    (2, 8, 256, 256, 40), (1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160), (2, 8, 64, 64, 160),
+    (2, 8, 100, 77, 40), (2, 8, 1024, 77, 80), (1, 8, 64, 77, 160), (2, 8, 192, 192, 8), (1, 4, 130, 200, 32), (2, 2, 70, 154, 64),
+    (2, 2, 200, 130, 96), (1, 2, 128, 192, 128), (1, 3, 90, 90, 16), (8, 8, 2304, 2304, 40), (8, 8, 2200, 2200, 40)])
+def test_attention_row_major_v(ops, b, heads, lq, lk, d):
+    c = heads * d
+    q, k, v = r16((b, lq, c), 51), r16((b, lk, c), 52), r16((b, lk, c), 53)
+    ref = O.attention(q.float(), k.float(), v.float(), heads)
+    y = ops.attention_rowv(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    assert rel_l2(y.float().cpu(), ref) < TOL
+    if lq == lk:
+        y = ops.attention_qkv(torch.cat([q, k, v], -1).to(DEV), heads)
+        assert rel_l2(y.float().cpu(), ref) < TOL
+
+
+def test_causal_attention_row_major_v(ops):
+    b, heads, l, d = 2, 8, 200, 40
+    q, k, v = r16((b, l, heads * d), 71), r16((b, l, heads * d), 72), r16((b, l, heads * d), 73)
+    y = ops.attention_rowv(q.to(DEV), k.to(DEV), v.to(DEV), heads, causal=True)
+    assert torch.equal(y, ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads, causal=True))   # same arithmetic, another V image
+
+
 def test_attention_softmax_rescale_branch(ops):
     """Force the running max to jump late (guide rule 26): one key far larger than the rest, placed in the last tile."""
     b, heads, l, d = 1, 2, 256, 40
