@@ -353,6 +353,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
     }
 }
 
+
 thread_local const char* t_last_attn_kernel = "";
 
 template <int DK, bool VROW>

@@ -170,7 +170,8 @@ def test_attention(ops, b, heads, lq, lk, d):
 @pytest.mark.parametrize("b,heads,lq,lk,d", [
     (2, 8, 256, 256, 40), (1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160), (2, 8, 64, 64, 160),
     (2, 8, 100, 77, 40), (2, 8, 1024, 77, 80), (1, 8, 64, 77, 160), (2, 8, 192, 192, 8), (1, 4, 130, 200, 32), (2, 2, 70, 154, 64),
-    (2, 2, 200, 130, 96), (1, 2, 128, 192, 128), (1, 3, 90, 90, 16), (8, 8, 2304, 2304, 40), (8, 8, 2200, 2200, 40)])
+    (2, 2, 200, 130, 96), (1, 2, 128, 192, 128), (1, 3, 90, 90, 16), (8, 8, 2304, 2304, 40), (8, 8, 2200, 2200, 40),
+    (8, 8, 2112, 2112, 40), (8, 8, 2176, 2176, 40), (8, 8, 2240, 2240, 40), (16, 8, 4096, 4096, 40)])   # the pipelined d = 40 kernel: 33 / 34 / 35 / 64 key tiles (ring of four)
 def test_attention_row_major_v(ops, b, heads, lq, lk, d):
     c = heads * d
     q, k, v = r16((b, lq, c), 51), r16((b, lk, c), 52), r16((b, lk, c), 53)
@@ -180,6 +181,22 @@ def test_attention_row_major_v(ops, b, heads, lq, lk, d):
     if lq == lk:
         y = ops.attention_qkv(torch.cat([q, k, v], -1).to(DEV), heads)
         assert rel_l2(y.float().cpu(), ref) < TOL
+
+
+def test_attention_pipelined_rescale_branch(ops):
+    """The pipelined d = 40 kernel (flash_attn3_kernel) when the softmax reference moves late: a few keys far larger than the rest in late
+    tiles, for some queries only — S^T of the next unit, O^T and the P still waiting for its PV product all have to follow."""
+    b, heads, l, d = 8, 8, 2304, 40
+    q, k, v = r16((b, l, heads * d), 54), r16((b, l, heads * d), 55), r16((b, l, heads * d), 56)
+    k[:, 2200] = q[:, 3] * 4.0
+    k[:, 1000] = q[:, 9] * 3.0
+    k[:, 70] = q[:, 700] * 5.0
+    k[:, 2303] = q[:, 2303] * 6.0
+    ref = O.attention(q.float(), k.float(), v.float(), heads)
+    y = ops.attention_rowv(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    assert rel_l2(y.float().cpu(), ref) < TOL
+    for rows in ([3], [9], [700], [2303]):                      # the rows whose reference moved, on their own
+        assert rel_l2(y[:, rows].float().cpu(), ref[:, rows]) < 2 * TOL
 
 
 def test_causal_attention_row_major_v(ops):
