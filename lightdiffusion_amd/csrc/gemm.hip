@@ -1156,7 +1156,7 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
 // at a time through the wave's slice of the (quiet) LDS, operands of a strip requested as one batch, predicated stores.
 template <int TM, int TN>
 __device__ __forceinline__ void v6_finish(const GemmParams& p, f32x4 (&acc)[TM][TN], char* smem5, int m0, int n0, int wm0, int wn0, int wid, int lane, int ks,
-                                          int splitk) {
+                                          int splitk, int gimg, int gchunk) {
     static_assert(TM == 4 || TM == 8, "wave tile of 64 or 128 rows");
     constexpr int WN = TN * 16, LD = WN + 4, STRIP_BYTES = 16 * LD * 2;
     constexpr int CPR = WN / 8, TOT = 16 * CPR, ITS = (TOT + 63) / 64;
@@ -1180,6 +1180,11 @@ __device__ __forceinline__ void v6_finish(const GemmParams& p, f32x4 (&acc)[TM][
     }
     half_t* Cs0 = reinterpret_cast<half_t*>(smem5 + wid * 2 * STRIP_BYTES);
     const bool hb = p.bias_n != nullptr, hv = p.rowvec != nullptr, hr = p.R != nullptr;
+    // GroupNorm statistics of the OUTPUT (GemmParams::gn_part, host-checked: whole tiles of one image, groups of 4 or of whole 8-channel
+    // chunks): a lane always handles the same 8-channel chunk, so it sums what it stores (the fp16-rounded values) over its rows —
+    // (sum, sum of squares) of channels 0-3 / 4-7 apart when a group is 4 channels wide — and the tile's partials are put together below
+    const bool gne = p.gn_part != nullptr, g4 = p.N == 128;
+    float gs[4] = {0.f, 0.f, 0.f, 0.f};
     auto stage = [&](auto I, half_t* dst) {
         constexpr int i = decltype(I)::value;
 #pragma unroll
@@ -1222,8 +1227,19 @@ __device__ __forceinline__ void v6_finish(const GemmParams& p, f32x4 (&acc)[TM][
                 else if (p.act == 3) t = quick_gelu_f(t);
                 v[j] = t + r[j];
             }
-            if ((TOT % 64 == 0 || q0 < TOT) && m_base + row < p.M && n_w + cc * 8 < p.n_valid)
-                st16(p.C + (long long)(m_base + row) * p.ldc + n_w + cc * 8, pack8(v));
+            if ((TOT % 64 == 0 || q0 < TOT) && m_base + row < p.M && n_w + cc * 8 < p.n_valid) {
+                const uint4 packed = pack8(v);
+                st16(p.C + (long long)(m_base + row) * p.ldc + n_w + cc * 8, packed);
+                if (gne) {   // v_dot2_f32_f16 on the packed pairs: 8 instructions per chunk
+                    const half2v one2 = {(half_t)1.f, (half_t)1.f};
+                    const half2v h0 = __builtin_bit_cast(half2v, packed.x), h1 = __builtin_bit_cast(half2v, packed.y);
+                    const half2v h2 = __builtin_bit_cast(half2v, packed.z), h3 = __builtin_bit_cast(half2v, packed.w);
+                    gs[0] = __builtin_amdgcn_fdot2(h1, one2, __builtin_amdgcn_fdot2(h0, one2, gs[0], false), false);     // channels 0-3
+                    gs[1] = __builtin_amdgcn_fdot2(h1, h1, __builtin_amdgcn_fdot2(h0, h0, gs[1], false), false);
+                    gs[2] = __builtin_amdgcn_fdot2(h3, one2, __builtin_amdgcn_fdot2(h2, one2, gs[2], false), false);     // channels 4-7
+                    gs[3] = __builtin_amdgcn_fdot2(h3, h3, __builtin_amdgcn_fdot2(h2, h2, gs[3], false), false);
+                }
+            }
         }
     };
     half_t* Cs1 = Cs0 + 16 * LD;
@@ -1243,6 +1259,36 @@ __device__ __forceinline__ void v6_finish(const GemmParams& p, f32x4 (&acc)[TM][
     if constexpr (TM == 8) {
         pair(std::integral_constant<int, 2>{});
         pair(std::integral_constant<int, 3>{});
+    }
+    if (gne && 64 % CPR == 0) {   // (workgroup-uniform; a lane keeps its chunk over the strips only when CPR divides 64: the host asks for it at BN = 256 / 128 only)
+        if (!g4) {   // groups of whole chunks: the two halves of the chunk belong together
+            gs[0] += gs[2];
+            gs[1] += gs[3];
+        }
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gs[k] += __shfl_xor(gs[k], o, 64);
+        }
+        float* wp = reinterpret_cast<float*>(smem5 + 8 * 2 * STRIP_BYTES);      // [8 waves][CPR chunks][4], behind every wave's strips
+        if (lane < CPR) *reinterpret_cast<float4*>(wp + (wid * CPR + lane) * 4) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+        __syncthreads();
+        // one thread per group of the tile: the four waves of its column half top to bottom, the group's chunks left to right (fixed order)
+        const int cpg = p.N / 32, tid = wid * 64 + lane;
+        if (tid < 2 * WN / cpg) {
+            const int col = tid * cpg, wn = col / WN, cf = (col - wn * WN) >> 3;
+            const int nch = cpg >= 8 ? cpg >> 3 : 1, part = (cpg == 4 && (col & 4)) ? 2 : 0;
+            float s = 0.f, ss = 0.f;
+            for (int wmi = 0; wmi < 4; ++wmi)
+                for (int c = 0; c < nch; ++c) {
+                    const float* e = wp + ((wmi * 2 + wn) * CPR + cf + c) * 4 + part;
+                    s += e[0];
+                    ss += e[1];
+                }
+            float* o = p.gn_part + (((long long)gimg * p.gn_P + gchunk) * 32 + (n0 + col) / cpg) * 2;
+            o[0] = s;
+            o[1] = ss;
+        }
     }
 }
 
@@ -1515,7 +1561,8 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     constexpr bool TBL_IN_HALO = 2 * HBYTES + NSTB * BSTAGE + 2048 > 163840;
     static_assert(!TBL_IN_HALO || NH * 8 - HPIECES >= 3, "two table slots and a dump slot");
     __shared__ __attribute__((aligned(16))) float gn_lds[(GN && !TBL_IN_HALO) ? 8 * 64 : 4];
-    static_assert(8 * 2 * (BN == V5_BN ? V5_EPI_BYTES : 16 * (BN / 2 + 4) * 2) <= 2 * HBYTES + NSTB * BSTAGE, "epilogue staging must fit");
+    static_assert(8 * 2 * (BN == V5_BN ? V5_EPI_BYTES : 16 * (BN / 2 + 4) * 2) + 8 * (BN / 16) * 16 <= 2 * HBYTES + NSTB * BSTAGE,
+                  "epilogue staging (+ the GroupNorm partials of the output) must fit");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1722,7 +1769,7 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     if (!grp1) __builtin_amdgcn_s_barrier();                            // group 0 waits out group 1's last MFMA phase
     if (GN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last ones retire before VALU reads the accumulators
     if constexpr (BN == V5_BN) v5_finish<0, false>(p, acc, smem5, nullptr, nullptr, 0, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
-    else v6_finish<TM, TN>(p, acc, smem5, m0, n0, wm0, wn0, wid, lane, ks, splitk);
+    else v6_finish<TM, TN>(p, acc, smem5, m0, n0, wm0, wn0, wid, lane, ks, splitk, img, t_in);
 }
 
 // =====================================================================================================================
@@ -2479,6 +2526,17 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         if (bn6 != 32) p.n_valid = p.N;                              // (the 32-column tile stores only the caller's n_valid columns)
         dim3 grid((unsigned)(t6 * sk6), 1, 1);
         const bool wide = p.Wo > 128;
+        if (sk6 == 1 && p.gn_part != nullptr) {
+            // the generic epilogue (v6_finish) also writes the GroupNorm partial statistics of the OUTPUT, one chunk per tile of an image
+            const int cpg = p.N / 32, tiles_img = (p.Ho / (pl.bm / wc)) * (p.Wo / wc);
+            const bool ok = (bn6 == 256 || bn6 == 128) && p.N % 32 == 0 && (p.N == 128 || cpg % 8 == 0) && bn6 % cpg == 0 && p.n_valid == p.N && p.act == 0;
+            if (ok) {
+                p.gn_P = tiles_img;
+                if (p.gn_part_done != nullptr) *p.gn_part_done = tiles_img;
+            } else {
+                p.gn_part = nullptr;
+            }
+        }
         if (p.gn_scale != nullptr) {
             if (p.gn_shift == nullptr || bn6 != V5_BN || pl.up) return LD_ERR_ARG;
             t_last_kernel = wc == 16 ? "conv6_kernel<W16,halo+groupnorm>" : wc == 32 ? "conv6_kernel<W32,halo+groupnorm>"

@@ -118,9 +118,19 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GnArgs a) {
         const int g = tid / lpg, sub = tid - g * lpg;
         float s = 0.f, ss = 0.f;
         const float* pp = a.partial + ((long long)n * a.Pstat * 32 + slab * gps + g) * 2;
-        for (int i = sub; i < a.Pstat; i += lpg) {
-            s += pp[(long long)i * 64];
-            ss += pp[(long long)i * 64 + 1];
+        for (int i = sub; i < a.Pstat; i += 4 * lpg) {   // four chunks per batch of loads (a producer's epilogue may have written up to 1024 chunks per image)
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int iu = i + u * lpg;
+                v[u] = *reinterpret_cast<const float2*>(pp + (long long)(iu < a.Pstat ? iu : sub) * 64);
+                if (iu >= a.Pstat) v[u] = make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += v[u].x;
+                ss += v[u].y;
+            }
         }
         for (int o = 1; o < lpg; o <<= 1) {
             s += __shfl_xor(s, o, 64);
@@ -186,9 +196,19 @@ __global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(const GnArgs a,
         const int g = tid / lpg, sub = tid - g * lpg;
         float s = 0.f, ss = 0.f;
         const float* pp = a.partial + ((long long)n * a.Pstat * 32 + slab * gps + g) * 2;
-        for (int i = sub; i < a.Pstat; i += lpg) {
-            s += pp[(long long)i * 64];
-            ss += pp[(long long)i * 64 + 1];
+        for (int i = sub; i < a.Pstat; i += 4 * lpg) {   // four chunks per batch of loads (a producer's epilogue may have written up to 1024 chunks per image)
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int iu = i + u * lpg;
+                v[u] = *reinterpret_cast<const float2*>(pp + (long long)(iu < a.Pstat ? iu : sub) * 64);
+                if (iu >= a.Pstat) v[u] = make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s += v[u].x;
+                ss += v[u].y;
+            }
         }
         for (int o = 1; o < lpg; o <<= 1) {
             s += __shfl_xor(s, o, 64);
@@ -303,6 +323,7 @@ size_t groupnorm_workspace_bytes(int n_img, int HW) {
     int P = gn_num_chunks(n_img, HW);
     const int p8 = HW / 16 < 256 ? HW / 16 : 256;               // a producer's epilogue may write 16-pixel chunks (conv8: HW / 16 per image, up to 64 x 64 images)
     if (p8 > P) P = p8;
+    if (HW / 256 > P) P = HW / 256;                             // ... or one chunk per 256-pixel tile (the halo convolution's generic epilogue)
     return (size_t)n_img * P * 32 * 2 * sizeof(float);
 }
 

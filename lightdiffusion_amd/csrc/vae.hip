@@ -164,8 +164,18 @@ struct VRun {
     int n;
     half_t* P(int s) const { return v->pt.ptr(s); }
 
+    // GroupNorm partial statistics of the tensor a convolution just wrote (its epilogue sums what it stores: gemm.h gn_part), for the
+    // GroupNorm that reads that tensor next: the statistics pass over it is skipped
+    const half_t* st_of = nullptr;
+    float* st_buf = nullptr;
+    int st_P = 0;
+    void gn(const half_t* x, int C, int HW, int gslot, int bslot, int silu, half_t* y) {
+        const bool ready = x == st_of && st_P > 0;
+        ex.groupnorm(x, C, nullptr, 0, n, HW, P(gslot), P(bslot), 1e-6f, silu, y, ready ? st_buf : nullptr, ready ? st_P : 0);
+    }
+
     void conv(const half_t* x, int cin, int Hs, int Ws, int Hv, int Wv, int ksize, int wslot, int bslot, int cout, const half_t* R, half_t* out,
-              int stride = 1, int pad = -1, int Ho = 0, int Wo = 0) {
+              int stride = 1, int pad = -1, int Ho = 0, int Wo = 0, float* stats = nullptr) {
         GemmParams p;
         p.conv = 1;
         p.ksize = ksize;
@@ -177,7 +187,19 @@ struct VRun {
         p.bias_n = P(bslot);
         p.R = R; p.ldr = cout;
         p.C = out; p.ldc = cout;
+        int done = 0;
+        if (stats != nullptr) {
+            p.gn_part = stats;
+            p.gn_part_done = &done;
+        }
         ex.gemm(p);
+        if (stats != nullptr) {
+            st_of = out;
+            st_buf = stats;
+            st_P = done;
+        } else if (out == st_of) {
+            st_of = nullptr;      // (the tensor the statistics described was overwritten)
+        }
     }
 
     // ResnetBlock.forward, LD.py:3560-3576 (GroupNorm eps 1e-6, swish)
@@ -185,20 +207,22 @@ struct VRun {
         Arena& ar = *ex.arena;
         const size_t M = (size_t)n * H * W;
         half_t* out = ar.halfs(M * r.cout);
+        float* so = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(n, H * W)));   // statistics of `out` (for the next GroupNorm)
         const size_t mk = ar.mark();
         half_t* g1 = ar.halfs(M * r.cin);
-        ex.groupnorm(x, r.cin, nullptr, 0, n, H * W, P(r.n1_g), P(r.n1_b), 1e-6f, 1, g1);
+        gn(x, r.cin, H * W, r.n1_g, r.n1_b, 1, g1);
         half_t* h1 = ar.halfs(M * r.cout);
-        conv(g1, r.cin, H, W, H, W, 3, r.c1_w, r.c1_b, r.cout, nullptr, h1);
+        float* s1 = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(n, H * W)));
+        conv(g1, r.cin, H, W, H, W, 3, r.c1_w, r.c1_b, r.cout, nullptr, h1, 1, -1, 0, 0, s1);
         half_t* g2 = r.cout <= r.cin ? g1 : ar.halfs(M * r.cout);
-        ex.groupnorm(h1, r.cout, nullptr, 0, n, H * W, P(r.n2_g), P(r.n2_b), 1e-6f, 1, g2);
+        gn(h1, r.cout, H * W, r.n2_g, r.n2_b, 1, g2);
         const half_t* skip = x;
         if (r.nin_w >= 0) {
             half_t* sk = h1;   // h1 is dead after norm2
             conv(x, r.cin, H, W, H, W, 1, r.nin_w, r.nin_b, r.cout, nullptr, sk);
             skip = sk;
         }
-        conv(g2, r.cout, H, W, H, W, 3, r.c2_w, r.c2_b, r.cout, skip, out);
+        conv(g2, r.cout, H, W, H, W, 3, r.c2_w, r.c2_b, r.cout, skip, out, 1, -1, 0, 0, so);
         ar.release(mk);
         return out;
     }
@@ -311,7 +335,8 @@ int run_decode(ld_vae* v, bool dry, const float* z, float* out, int b, int h, in
         }
         if (lvl != 0) {   // Upsample: nearest 2x then conv (LD.py:3498-3511), fused into the conv's loader
             half_t* o = ar.halfs((size_t)b * 4 * H * W * C);
-            R.conv(f, C, H, W, 2 * H, 2 * W, 3, v->ups_w[lvl], v->ups_b[lvl], C, nullptr, o);
+            float* so = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(b, 4 * H * W)));
+            R.conv(f, C, H, W, 2 * H, 2 * W, 3, v->ups_w[lvl], v->ups_b[lvl], C, nullptr, o, 1, -1, 0, 0, so);
             f = o;
             H *= 2;
             W *= 2;
@@ -319,7 +344,7 @@ int run_decode(ld_vae* v, bool dry, const float* z, float* out, int b, int h, in
     }
     {
         half_t* g = ar.halfs((size_t)b * H * W * C);
-        ex.groupnorm(f, C, nullptr, 0, b, H * W, v->pt.ptr(v->no_g), v->pt.ptr(v->no_b), 1e-6f, 1, g);
+        R.gn(f, C, H * W, v->no_g, v->no_b, 1, g);
         // conv_out (C -> 3): on the halo-tile MFMA kernel when the image is cut into its 4-row x 128-pixel tiles (weights zero-padded to
         // 32 rows, 8 stored columns, then one elementwise pass for clamp((v + 1) / 2) -> fp32 NHWC): 1427 -> ~200 us at 512x512 x 8;
         // other sizes keep the vector-ALU kernel
@@ -418,7 +443,7 @@ int run_encode(ld_vae* v, bool dry, const float* px, float* moments, int b, int 
     f = R.resblock(v->e_mid2, f, H, W);
     {
         half_t* g = ar.halfs((size_t)b * H * W * C);
-        ex.groupnorm(f, C, nullptr, 0, b, H * W, v->pt.ptr(v->e_no_g), v->pt.ptr(v->e_no_b), 1e-6f, 1, g);
+        R.gn(f, C, H * W, v->e_no_g, v->e_no_b, 1, g);
         const int Z2 = 2 * c.z_channels;
         half_t* m = ar.halfs((size_t)b * H * W * Z2);
         R.conv(g, C, H, W, H, W, 3, v->e_co_w, v->e_co_b, Z2, nullptr, m);
