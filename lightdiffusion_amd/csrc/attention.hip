@@ -28,8 +28,10 @@
 
 #include "kernels.h"
 // Ablation builds behind profiles/README.md ("no exp", "no tile sync", "1 of 4 PV MFMAs", "2 of 7 fragment reads"): -DLD_ATT_DBG=1..4.
-// They compute WRONG results on purpose (timing only) and are never part of the shipped library.
-#ifndef LD_ATT_DBG
+// They compute WRONG results on purpose (timing only) and exist in the A/B build (make ab, -DLD_AB_BUILD) only: the shipped library
+// ignores the macro.
+#if !defined(LD_AB_BUILD) || !defined(LD_ATT_DBG)
+#undef LD_ATT_DBG
 #define LD_ATT_DBG 0
 #endif
 

@@ -17,7 +17,8 @@
 #include "gemm.h"
 // Ablation build behind profiles/README.md: -DLD_DBG=6 makes every workgroup stream the SAME tile (all loads hit cache; wrong results,
 // timing only).  Never part of the shipped library.
-#ifndef LD_DBG
+#if !defined(LD_AB_BUILD) || !defined(LD_DBG)   // (A/B build only: the shipped library ignores the macro)
+#undef LD_DBG
 #define LD_DBG 0
 #endif
 

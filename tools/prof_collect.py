@@ -32,9 +32,12 @@ def short_name(k):
     m = re.match(r"gemm7_kernel<(true|false)(?:, (?:true|false))?>", k)
     if m:
         return f"gemm7_kernel<256,K320,{'geglu' if m.group(1) == 'true' else 'plain'}>"
-    m = re.match(r"flash_attn2_kernel<(\d+), (true|false), (\d+), \d+>", k)
+    m = re.match(r"flash_attn2_kernel<(\d+), (true|false), (\d+), \d+(?:, (true|false))?>", k)
     if m:
-        return f"flash_attn2_kernel<{m.group(1)},{'masked' if m.group(2) == 'true' else 'plain'},{m.group(3)}>"
+        return f"flash_attn2_kernel<{m.group(1)}{',rowV' if m.group(4) == 'true' else ''},{'masked' if m.group(2) == 'true' else 'plain'},{m.group(3)}>"
+    m = re.match(r"conv8_kernel<(\d+), (true|false)>", k)
+    if m:
+        return f"conv8_kernel<W{m.group(1)}{',up' if m.group(2) == 'true' else ''}>"
     return re.sub(r"\(.*$", "", k)
 
 

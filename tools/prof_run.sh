@@ -35,6 +35,11 @@ if [ "$WHAT" != "kernel" ]; then
       timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_${W}_$n -- python3 bench.py --only $W --no-graph --no-prime --steps 2 --warmup 1 --reps 0 --sync-steps > $O/${TAG}_pmc_${W}_$n.log 2>&1 || { echo "pmc $W $n failed"; tail -3 $O/${TAG}_pmc_${W}_$n.log; exit 1; }
       echo "pmc $W $n done"
     done
+    if [ "$W" = "batch8" ]; then
+      # co-execution / wait / LDS-instruction counters (round 4; a counter this rocprofiler build does not know only loses this pass)
+      C="SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+      timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_${W}_SQ_VALU_MFMA_COEXEC_CYCLES -- python3 bench.py --only $W --no-graph --no-prime --steps 2 --warmup 1 --reps 0 --sync-steps > $O/${TAG}_pmc_${W}_coexec.log 2>&1 && echo "pmc $W coexec done" || { echo "pmc $W coexec pass failed (kept going)"; tail -3 $O/${TAG}_pmc_${W}_coexec.log; rm -rf $O/${TAG}_pmc_${W}_SQ_VALU_MFMA_COEXEC_CYCLES; }
+    fi
     python3 tools/prof_collect.py pmc $W $O/${TAG}_${W}_pmc.csv $O/${TAG}_pmc_${W}_*/ && cp $O/${TAG}_${W}_pmc.csv profiles/
   done
   for V in "8 64 vae512"; do
