@@ -98,6 +98,9 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               f"or `make -C lightdiffusion_amd/csrc`.  There is no CPU / PyTorch fallback for the hot path.")
+        # torch first: it brings its own libamdhip64; loaded the other way round (this library first, resolved against /opt/rocm) the
+        # process ends up with two HIP runtimes and the first hipMalloc here fails (seen with build() + smoke() in one process)
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             if os.environ.get("LD_MI355X_LIB") and not hasattr(l, name):
