@@ -140,6 +140,14 @@ int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, 
                          const void* wt, const void* bias, const void* rowvec, const void* residual, void* y, int cout, void* ws,
                          size_t ws_bytes, void* stream);
 int ld_op_repack_conv(const void* src_oihw, int dtype, int cout, int cin, void* dst, void* stream);
+/* 3x3 stride-1 convolution (hv = 2h: behind a nearest-2x upsampling) that also returns the GroupNorm(32) partial statistics of its OUTPUT
+ * where the kernel that runs the shape writes them (the halo convolution's generic epilogue, the row-resident kernel, the split-K second
+ * pass) — what lets the GroupNorm that follows (ResBlock1 out_layers / the next block's in_layers, LD.py:5224-5262; the VAE's ResnetBlock,
+ * LD.py:3560-3576) skip its statistics pass.  part: [n][*chunks][32][2] floats (sum, sum of squares per image, pixel chunk, group), sized
+ * ld_op_conv_gn_partials_floats(n, hv*wv); *chunks = 0 when this shape's kernel does not write them.  For parity tests. */
+size_t ld_op_conv_gn_partials_floats(int n, int hw);
+int ld_op_conv_gn_partials(const void* x, int c, int n, int h, int w, int hv, int wv, const void* wt, const void* bias,
+                           const void* residual, void* y, int cout, float* part, int* chunks, void* ws, size_t ws_bytes, void* stream);
 /* GroupNorm(32) over the channel concat of two NHWC sources (+ optional SiLU); ws >= ld_op_groupnorm_ws_bytes */
 size_t ld_op_groupnorm_ws_bytes(int n, int hw);
 int ld_op_groupnorm(const void* x1, int c1, const void* x2, int c2, int n, int hw, const void* gamma, const void* beta,

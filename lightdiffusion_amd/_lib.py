@@ -80,6 +80,8 @@ SIGNATURES = {
     "ld_op_groupnorm": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P]),
     "ld_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "ld_op_attention": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "ld_op_conv_gn_partials_floats": (_Z, [_I, _I]),
+    "ld_op_conv_gn_partials": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _Z, _P]),
     "ld_op_attention_rowv": (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "ld_op_softmax_rows": (_I, [_P, _I, _I, _P]),
     "ld_op_timestep_embed": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),

@@ -62,11 +62,19 @@ int ld_op_linear(const void* x, const void* w, const void* bias, const void* res
     return gemm_launch(p, stream);
 }
 
-int ld_op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int w, int hv, int wv, int stride, int ksize,
-               const void* wt, const void* bias, const void* rowvec, const void* residual, void* y, int cout, void* ws,
-               size_t ws_bytes, void* stream) {
+static int op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int w, int hv, int wv, int stride, int ksize,
+                   const void* wt, const void* bias, const void* rowvec, const void* residual, void* y, int cout, void* ws,
+                   size_t ws_bytes, void* stream, float* gn_part, int* gn_chunks) {
     if (stride < 1 || (ksize != 1 && ksize != 3)) return LD_ERR_ARG;
     GemmParams p;
+    if (gn_part != nullptr) {   // GroupNorm partial statistics of the output, where the kernel that runs this shape writes them (as the executors ask: unet.hip want_stats)
+        const int HW = (ksize == 3 ? (hv - 1) / stride + 1 : hv) * (ksize == 3 ? (wv - 1) / stride + 1 : wv);
+        p.gn_part = gn_part;
+        p.gn_P = gn_num_chunks(n, HW);
+        p.gn_HW = HW;
+        p.gn_ppb = (HW + p.gn_P - 1) / p.gn_P;
+        p.gn_part_done = gn_chunks;
+    }
     p.conv = 1;
     p.ksize = ksize;
     p.A = (const half_t*)x1; p.A2 = (const half_t*)x2; p.C1 = c1; p.C2 = c2;
@@ -100,6 +108,21 @@ int ld_op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int
         }
     }
     return gemm_launch(p, (hipStream_t)stream);
+}
+
+int ld_op_conv(const void* x1, int c1, const void* x2, int c2, int n, int h, int w, int hv, int wv, int stride, int ksize,
+               const void* wt, const void* bias, const void* rowvec, const void* residual, void* y, int cout, void* ws,
+               size_t ws_bytes, void* stream) {
+    return op_conv(x1, c1, x2, c2, n, h, w, hv, wv, stride, ksize, wt, bias, rowvec, residual, y, cout, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+size_t ld_op_conv_gn_partials_floats(int n, int hw) { return groupnorm_workspace_bytes(n, hw) / sizeof(float); }
+
+int ld_op_conv_gn_partials(const void* x, int c, int n, int h, int w, int hv, int wv, const void* wt, const void* bias, const void* residual,
+                           void* y, int cout, float* part, int* chunks, void* ws, size_t ws_bytes, void* stream) {
+    if (part == nullptr || chunks == nullptr) return LD_ERR_ARG;
+    *chunks = 0;
+    return op_conv(x, c, nullptr, 0, n, h, w, hv, wv, 1, 3, wt, bias, nullptr, residual, y, cout, ws, ws_bytes, stream, part, chunks);
 }
 
 size_t ld_op_groupnorm_conv_ws_bytes(int c1, int c2, int n, int h, int w, int cout) {

@@ -121,6 +121,26 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]
     return y
 
 
+def conv2d_gn_partials(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], out_hw: Optional[tuple] = None,
+                       residual: Optional[torch.Tensor] = None):
+    """3x3 stride-1 NHWC conv that also returns the GroupNorm(32) partial statistics its kernel wrote for the OUTPUT:
+    (y, part [n, chunks, 32, 2] fp32 or None when this shape's kernel writes none) — what the executors hand to the next GroupNorm
+    (ResBlock1, LD.py:5224-5262; ResnetBlock, LD.py:3560-3576) instead of a statistics pass."""
+    import ctypes
+    n, h, w, c = x.shape
+    hv, wv = (h, w) if out_hw is None else out_hw
+    cout = w_packed.shape[0]
+    y = torch.empty(n, hv, wv, cout, dtype=torch.float16, device=x.device)
+    part = torch.zeros(lib().ld_op_conv_gn_partials_floats(n, hv * wv), dtype=torch.float32, device=x.device)
+    chunks = ctypes.c_int(0)
+    ws = _ws(192 << 20, x.device)
+    check(lib().ld_op_conv_gn_partials(_p(x), c, n, h, w, hv, wv, _p(w_packed), _p(bias), _p(residual), _p(y), cout, _p(part), ctypes.byref(chunks),
+                                       _p(ws), ws.numel(), _stream()), "ld_op_conv_gn_partials")
+    if chunks.value == 0:
+        return y, None
+    return y, part[: n * chunks.value * 64].view(n, chunks.value, 32, 2)
+
+
 def group_norm_silu_conv2d(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, w_packed: torch.Tensor,
                            bias: Optional[torch.Tensor], x2: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None,
                            residual: Optional[torch.Tensor] = None) -> torch.Tensor:

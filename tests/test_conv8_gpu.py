@@ -101,3 +101,37 @@ def test_conv_row_resident(ops, n, hw, cin, cout, up, rv, res):
     y = ops.conv2d(nhwc(x).to(DEV), ops.repack_conv_weight(wt.to(DEV)), b.to(DEV), 3, 1, None, (hw, hw) if up else None,
                    None if rowvec is None else rowvec.to(DEV), None if r is None else nhwc(r).to(DEV))
     assert rel_l2(nchw(y.float().cpu()), ref.cpu()) < TOL
+
+
+# GroupNorm partial statistics written by the PRODUCING convolution (so the GroupNorm that follows runs one pass): every kernel that writes
+# them — the halo convolution's generic epilogue at 256- and 128-column tiles (the VAE decoder's stages, LD.py:3560-3576; also behind the
+# nearest-2x upsampling), the row-resident kernel (two-image levels of the UNet) and the split-K second pass (8 x 8 level at UNet batch 16).
+# Checked against the statistics of the tensor the kernel stored: per (image, group) sum and sum of squares over all chunks, in fp64.
+@pytest.mark.parametrize("n,hw,cin,cout,up,res,expect", [
+    (8, 64, 512, 512, False, True, True),        # conv6 <W64, 256-column tiles>: 16-channel groups = two 8-channel chunks
+    (4, 128, 256, 256, False, False, True),      # conv6 <W128, 256>: 8-channel groups
+    (2, 256, 128, 128, False, True, True),       # conv6 <W128, 128 x 512 tiles>: 4-channel groups, two per chunk; image cut into 128-pixel bands
+    (4, 128, 256, 256, True, False, True),       # ... behind the nearest-2x upsampling (64 -> 128)
+    (2, 16, 1280, 1280, False, True, True),      # conv8: 16-pixel chunks
+    (2, 64, 320, 320, False, False, True),       # conv8 at 64 x 64
+    (16, 8, 1280, 1280, False, True, True)])     # 128 x 160 kernel + split-K reduce with GroupNorm partials
+def test_conv_writes_groupnorm_partials_of_its_output(ops, n, hw, cin, cout, up, res, expect):
+    hs = hw // 2 if up else hw
+    x = r16((n, cin, hs, hs), 221)
+    wt, b = r16((cout, cin, 3, 3), 222, 1 / math.sqrt(9 * cin)), r16((cout,), 223, 0.1)
+    r = r16((n, cout, hw, hw), 224) if res else None
+    y, part = ops.conv2d_gn_partials(nhwc(x).to(DEV), ops.repack_conv_weight(wt.to(DEV)), b.to(DEV), (hw, hw) if up else None,
+                                     None if r is None else nhwc(r).to(DEV))
+    xin = x.float().to(DEV)
+    if up:
+        xin = F.interpolate(xin, size=(hw, hw), mode="nearest")
+    ref = F.conv2d(xin, wt.float().to(DEV), b.float().to(DEV), padding=1)
+    if res:
+        ref = ref + r.float().to(DEV)
+    assert rel_l2(nchw(y.float().cpu()), ref.cpu()) < TOL
+    assert (part is not None) == expect
+    got = part.double().sum(1)                                          # [n, 32, 2]
+    yg = y.double().view(n, hw * hw, 32, cout // 32)                     # the STORED fp16 values, grouped
+    want = torch.stack([yg.sum((1, 3)), (yg * yg).sum((1, 3))], -1)
+    assert float((got[..., 0] - want[..., 0]).abs().max()) < 1e-3 * float(yg.abs().sum((1, 3)).max())
+    assert float(((got[..., 1] - want[..., 1]).abs() / want[..., 1]).max()) < 1e-4
