@@ -85,7 +85,7 @@ __global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p
     const int NTN = p.N / C8_BN, S = p.c8_S, TMS = p.M / 128;
 #ifdef LD_AB_BUILD
     // phase clocks (tools/conv8_phases.py): waves 0 and 4 of every workgroup stamp s_memrealtime (100 MHz) at the phase boundaries
-    unsigned long long* const sbase = p.dbg ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.partial) + p.partial_bytes - 65536) + blockIdx.x * 32 : nullptr;
+    unsigned long long* const sbase = (p.dbg & 1) ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.partial) + p.partial_bytes - 65536) + blockIdx.x * 32 : nullptr;
     unsigned long long* const stamps = sbase != nullptr ? sbase + (tid >= 256 ? 8 : 0) : nullptr;   // wave 0: [0..7], wave 4: [8..15]; [16..]: wait-time sums
 #define C8_STAMP(i) do { if (stamps != nullptr && (tid == 0 || tid == 256)) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     unsigned long long acc_a = 0, acc_b = 0, tmark = 0;   // shader-clock sums of the time a wave spends in its barrier / in its vmcnt wait
@@ -436,7 +436,10 @@ __global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p
     if (tid == 0) {
         const int t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 1;
-        if (t != S - 1) {                                       // not the last arriver: wait (bounded) until every slab of the tile is there
+#ifdef LD_AB_BUILD
+        if ((p.dbg & 2) && t != S - 1) ok = 0;                  // LD_C8_NO_WAIT=1 (tools/conv8_timeout_check.py): behave as if no peer were resident — the last arriver reduces the whole tile alone
+#endif
+        if (ok && t != S - 1) {                                 // not the last arriver: wait (bounded) until every slab of the tile is there
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) {
                 __builtin_amdgcn_s_sleep(2);
@@ -626,7 +629,7 @@ int conv8_launch(const GemmParams& pin, hipStream_t stream) {
     p.c8_S = S;
     p.pad = 1;
 #ifdef LD_AB_BUILD
-    p.dbg = getenv("LD_C8_STAMPS") != nullptr && p.partial_bytes > ((size_t)1 << 20);
+    p.dbg = (getenv("LD_C8_STAMPS") != nullptr && p.partial_bytes > ((size_t)1 << 20) ? 1 : 0) | (getenv("LD_C8_NO_WAIT") != nullptr ? 2 : 0);
 #endif
     if (p.bias_n == nullptr || p.rowvec == nullptr || p.R == nullptr) {
         static const half_t* zero_page = nullptr;
