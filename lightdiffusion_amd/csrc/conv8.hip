@@ -230,6 +230,9 @@ __global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p
             C8_TB();                                            // (time in the vmcnt wait)
             __builtin_amdgcn_s_barrier();
             C8_TA();                                            // (time in the barrier)
+#ifdef LD_AB_BUILD
+            if (p.dbg & 32) continue;
+#endif
             if (k + C8_RING - 1 < nloc) w_issue((k + C8_RING - 1) & (C8_RING - 1));   // into the stage that was read in iteration k - 1
         }
 #ifdef LD_AB_BUILD
@@ -248,6 +251,9 @@ __global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p
             // during group g: group g + 1 (loaded a group ago) goes into the other buffer — its previous contents were read before the barrier
             // that opened this group — and the loads of group g + 2 go out into the registers that just became free; first half of the
             // chunks in the group's first iteration, second half in its second one
+#ifdef LD_AB_BUILD
+            if (p.dbg & 16) continue;
+#endif
             if (2 * g + 2 < nloc) {
                 const bool more = 2 * g + 4 < nloc;
                 if (g & 1) {
@@ -305,15 +311,27 @@ __global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p
             C8_TA();
             const char* wst = wring + (k & (C8_RING - 1)) * C8_WSTAGE + b_lane;
             const char* hb = halo + ((k >> 1) & 1) * GROUP_B + (k & 1) * PLANE_B;
-            read_frags(wst, hb, 0, 0);
-            read_frags(wst, hb, 1, 1);
+#ifdef LD_AB_BUILD
+            const bool no_rd = (p.dbg & 4) != 0, no_mm = (p.dbg & 8) != 0;
+            if (!no_rd || k == 0)
+#endif
+            {
+                read_frags(wst, hb, 0, 0);
+                read_frags(wst, hb, 1, 1);
+            }
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
                 // the fragments of step t are in: everything but the seven reads of step t + 1 (issued behind the MFMAs of step t - 1)
                 if (t + 1 < 5) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef LD_AB_BUILD
+                if (!no_rd || k == 0)
+#endif
                 if (t + 2 < 5) read_frags(wst, hb, t + 2, (t + 2) % 3);
+#ifdef LD_AB_BUILD
+                if (!no_mm)
+#endif
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -629,7 +647,8 @@ int conv8_launch(const GemmParams& pin, hipStream_t stream) {
     p.c8_S = S;
     p.pad = 1;
 #ifdef LD_AB_BUILD
-    p.dbg = (getenv("LD_C8_STAMPS") != nullptr && p.partial_bytes > ((size_t)1 << 20) ? 1 : 0) | (getenv("LD_C8_NO_WAIT") != nullptr ? 2 : 0);
+    p.dbg = (getenv("LD_C8_STAMPS") != nullptr && p.partial_bytes > ((size_t)1 << 20) ? 1 : 0) | (getenv("LD_C8_NO_WAIT") != nullptr ? 2 : 0) |
+            (getenv("LD_C8_ABL") != nullptr ? atoi(getenv("LD_C8_ABL")) << 2 : 0);   // ablations (tools/conv8_abl.py; wrong results, timing only): 1 no fragment reads, 2 no MFMAs, 4 no halo staging, 8 no weight DMA in the loop
 #endif
     if (p.bias_n == nullptr || p.rowvec == nullptr || p.R == nullptr) {
         static const half_t* zero_page = nullptr;
