@@ -1,6 +1,7 @@
 // conv8: row-resident 3x3 convolution (stride 1, pad 1, optional nearest-2x upsampling of the input) for launches whose M is too small
 // to fill the chip with the big-tile kernels — every ResBlock1 convolution (LD.py:5189-5287) and Upsample1 convolution (LD.py:5141-5152)
-// of a batch-1 step (UNet batch 2) on all four levels, and the 8x8 level up to UNet batch 16.
+// of a batch-1 step (UNet batch 2, the CFG pair) on all four levels (conv8_plan declines more than two images: at UNet batch 16 the 8x8
+// level measured 0.1 ms per forward behind the general kernels).
 //
 // Why a separate kernel: at M = 128 .. 8192 rows the 64 x 160 tiles of the general kernel + a split over K + a reduce launch + the
 // GroupNorm launches in front run at 10-20 % of either roof (profiles/README.md round 4): every weight byte is re-read once per M tile and
