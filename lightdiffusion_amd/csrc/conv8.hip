@@ -16,7 +16,7 @@
 //     every run pulls its whole 128-byte line from HBM, and the line is evicted before the next sub-slab asks for it);
 //   * the activations sit in LDS as a zero-bordered halo image per 16-channel plane, staged through registers by waves 4-7 in groups of
 //     two planes (64 contiguous bytes per pixel), double buffered, loaded one group ahead; waves 8-11 issue the weight DMA (a four-stage
-//     ring, three stages in flight); waves 0-3 only read fragments and issue MFMAs.  (A variant that also applied the GroupNorm + SiLU of the
+//     ring = two groups of two stages, the next group in flight); waves 0-3 only read fragments and issue MFMAs.  (A variant that also applied the GroupNorm + SiLU of the
 //     input while staging the halo — no gn_apply launch — is kept in tools/experiments/conv8_fused_groupnorm_r04.hip.txt: correct, but the
 //     normalisation is vector-ALU work on the SIMDs that issue the MFMAs, the two ADD on this chip, and every N tile repeats it:
 //     5.32 vs 5.19 ms per batch-1 forward, profiles/README.md round 4.)
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p
     // ------------------------------------------------------------------------------------------ prologue
     if (wid >= 8) {
 #pragma unroll
-        for (int k = 0; k < C8_RING - 1; ++k)
+        for (int k = 0; k < C8_RING; ++k)
             if (k < nloc) w_issue(k);
     } else if (halo_wave) {
         halo_load(0, hregA, U0{}, UN{});
@@ -211,8 +211,9 @@ __global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p
     if (halo_wave) halo_store(0, 0, hregA, U0{}, UN{});
     C8_STAMP(1);
 
-    // ------------------------------------------------------------------------------------------ main loop: one 16-channel sub-slab per barrier
-    // Three roles with SEPARATE code paths (one s_barrier per sub-slab joins them): waves 0-3 = consumers — fragment reads and MFMA only
+    // ------------------------------------------------------------------------------------------ main loop: 16-channel sub-slabs, one barrier per two
+    // Three roles with SEPARATE code paths (one s_barrier per GROUP of two sub-slabs joins them — the ring holds two groups of weight stages, the halo
+    // buffers two groups of planes; with a barrier per sub-slab the batch-1 forward measured 0.6 % slower, profiles/r04_ab_conv8.txt): waves 0-3 = consumers — fragment reads and MFMA only
     // (wave w owns rows 32 w .. 32 w + 31 of the patch: two 16-row tiles x five 16-column tiles); waves 4-7 = the halo staging with its
     // global loads; waves 8-11 = the weight DMA with its counted waits.  Measured on the way here (profiles/README.md round 4): with shared
     // code hipcc parks a vmcnt(0) for the halo registers in front of every fragment read, which drains the weight ring each sub-slab
@@ -225,16 +226,28 @@ __global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p
         for (int jj = 0; jj < 5; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (wid >= 8) {           // ---- weight DMA: stage k + 3 goes out as soon as everybody is past stage k - 1 (three stages in flight)
-        for (int k = 0; k < nloc; ++k) {
+        // one barrier per GROUP of two sub-slabs (k even): the consumers run the group's second sub-slab without meeting the other roles again.
+        // The four ring slots hold two groups: group g + 1 goes out behind the barrier of group g into the slots group g - 1 was read from
+        // (groups 0 and 1 went out in the prologue), and has one group of the loop to land.
+        for (int k = 0; k < nloc; k += 2) {
             C8_T0();
-            w_wait(nloc - 1 - k);
+            if (k == 0 && nloc > 2) {                           // group 1 (one or two stages) may still be in flight
+                const bool two = nloc > 3;
+                if (wd == 0) { if (two) wait_vmcnt<14>(); else wait_vmcnt<7>(); }
+                else { if (two) wait_vmcnt<12>(); else wait_vmcnt<6>(); }
+            } else {
+                wait_vmcnt<0>();
+            }
             C8_TB();                                            // (time in the vmcnt wait)
             __builtin_amdgcn_s_barrier();
             C8_TA();                                            // (time in the barrier)
 #ifdef LD_AB_BUILD
             if (p.dbg & 32) continue;
 #endif
-            if (k + C8_RING - 1 < nloc) w_issue((k + C8_RING - 1) & (C8_RING - 1));   // into the stage that was read in iteration k - 1
+            if (k >= 2) {
+                if (k + 2 < nloc) w_issue((k + 2) & (C8_RING - 1));
+                if (k + 3 < nloc) w_issue((k + 3) & (C8_RING - 1));
+            }
         }
 #ifdef LD_AB_BUILD
         if (sbase != nullptr && tid == 512) { sbase[18] = acc_a; sbase[19] = acc_b; }
@@ -244,10 +257,12 @@ __global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p
         // at priority 1 they overlap — tools/micro/coexec.hip, profiles/README.md)
         __builtin_amdgcn_s_setprio(1);
         for (int k = 0; k < nloc; ++k) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's halo writes of the group that starts here
-            C8_T0();
-            __builtin_amdgcn_s_barrier();
-            C8_TA();
+            if (!(k & 1)) {                                     // (one barrier per group: see the weight DMA loop)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's halo writes of the group that starts here
+                C8_T0();
+                __builtin_amdgcn_s_barrier();
+                C8_TA();
+            }
             const int g = k >> 1;
             // during group g: group g + 1 (loaded a group ago) goes into the other buffer — its previous contents were read before the barrier
             // that opened this group — and the loads of group g + 2 go out into the registers that just became free; first half of the
@@ -307,9 +322,11 @@ __global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p
         const unsigned long long loop_t0 = sbase != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
         for (int k = 0; k < nloc; ++k) {
-            C8_T0();
-            __builtin_amdgcn_s_barrier();
-            C8_TA();
+            if (!(k & 1)) {                                     // (one barrier per group: see the weight DMA loop)
+                C8_T0();
+                __builtin_amdgcn_s_barrier();
+                C8_TA();
+            }
             const char* wst = wring + (k & (C8_RING - 1)) * C8_WSTAGE + b_lane;
             const char* hb = halo + ((k >> 1) & 1) * GROUP_B + (k & 1) * PLANE_B;
 #ifdef LD_AB_BUILD
