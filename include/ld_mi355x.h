@@ -140,6 +140,14 @@ int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, 
                          const void* wt, const void* bias, const void* rowvec, const void* residual, void* y, int cout, void* ws,
                          size_t ws_bytes, void* stream);
 int ld_op_repack_conv(const void* src_oihw, int dtype, int cout, int cin, void* dst, void* stream);
+/* ResBlock1's out_layers convolution and its 1x1 skip_connection as ONE contraction (LD.py:5267, 5273-5287; the UNet executor's "skip
+ * fold"):  y = conv3x3(x; wt) + bias + conv1x1(cat(s1, s2); wskip) + bskip (+ rowvec per image), stride 1, pad 1.  x [n][h][w][c];
+ * s1 / s2 raw NHWC sources of the same spatial size with sc1 / sc2 channels (s2 may be NULL with sc2 = 0); wt [cout][9c] as ld_op_repack_conv
+ * writes it; wskip [cout][sc1 + sc2].  The skip channels are a second segment of the K axis: the weights are concatenated to
+ * [cout][9c + sc1 + sc2] in `ws` first (the executor keeps that copy resident).  ws >= ld_op_conv_skip_ws_bytes(...). */
+size_t ld_op_conv_skip_ws_bytes(int c, int sc1, int sc2, int cout);
+int ld_op_conv_skip(const void* x, int c, int n, int h, int w, const void* wt, const void* bias, const void* s1, int sc1, const void* s2, int sc2,
+                    const void* wskip, const void* bskip, const void* rowvec, void* y, int cout, void* ws, size_t ws_bytes, void* stream);
 /* 3x3 stride-1 convolution (hv = 2h: behind a nearest-2x upsampling) that also returns the GroupNorm(32) partial statistics of its OUTPUT
  * where the kernel that runs the shape writes them (the halo convolution's generic epilogue, the row-resident kernel, the split-K second
  * pass) — what lets the GroupNorm that follows (ResBlock1 out_layers / the next block's in_layers, LD.py:5224-5262; the VAE's ResnetBlock,

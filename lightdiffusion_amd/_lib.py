@@ -76,6 +76,8 @@ SIGNATURES = {
     "ld_op_groupnorm_conv_ws_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "ld_op_groupnorm_conv": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "ld_op_repack_conv": (_I, [_P, _I, _I, _I, _P, _P]),
+    "ld_op_conv_skip_ws_bytes": (_Z, [_I, _I, _I, _I]),
+    "ld_op_conv_skip": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _Z, _P]),
     "ld_op_groupnorm_ws_bytes": (_Z, [_I, _I]),
     "ld_op_groupnorm": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _F, _I, _P, _P, _P]),
     "ld_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
@@ -100,18 +102,37 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               f"or `make -C lightdiffusion_amd/csrc`.  There is no CPU / PyTorch fallback for the hot path.")
-        # torch first: it brings its own libamdhip64; loaded the other way round (this library first, resolved against /opt/rocm) the
-        # process ends up with two HIP runtimes and the first hipMalloc here fails (seen with build() + smoke() in one process)
-        import torch  # noqa: F401
+        # Runtime resolution order: the library is linked against libamdhip64 without an rpath, so it binds to whichever HIP runtime the
+        # process has loaded already, else to the loader's default (/opt/rocm/lib).  PyTorch ships its OWN libamdhip64: when torch is
+        # present it must be loaded first — the other way round the process ends up with two HIP runtimes and the first hipMalloc here
+        # fails (seen with build() + smoke() in one process).  A pure C-ABI / ctypes host without PyTorch gets the system runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
+        missing = []
         for name, (res, args) in SIGNATURES.items():
-            if os.environ.get("LD_MI355X_LIB") and not hasattr(l, name):
-                continue                   # an older commit's library named for a same-box comparison (tools/build_ref_lib.sh): fewer entry points
-            fn = getattr(l, name)          # AttributeError here = header and library out of sync
+            if not hasattr(l, name):
+                if not os.environ.get("LD_MI355X_LIB"):
+                    raise AttributeError(f"{LIB_PATH} does not export {name}: header and library out of sync — rebuild it")
+                # an older commit's library named for a same-box comparison (tools/build_ref_lib.sh) has fewer entry points: a call of a
+                # missing one fails with a clear message instead of an AttributeError deep inside ctypes
+                missing.append(name)
+                setattr(l, name, _missing_symbol(name))
+                continue
+            fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        l._ld_missing = tuple(missing)
         _lib = l
     return _lib
+
+
+def _missing_symbol(name: str):
+    def fail(*_a, **_k):
+        raise RuntimeError(f"{LIB_PATH} (LD_MI355X_LIB) does not export {name}: it was built from a commit without this entry point")
+    return fail
 
 
 def check(status: int, where: str) -> None:

@@ -394,9 +394,15 @@ int attention_launch(const AttnParams& p, hipStream_t stream) {
     // 16-byte row copies: every row start must be 16-byte aligned; V^T rows are read in 8-key chunks, so the
     // V^T buffer must be allocated (and zero-padded) to a multiple of 8 keys per row
     if ((p.ldq & 7) || (p.ldk & 7) || (p.ldo & 3) || (p.sQ & 7) || (p.sK & 7) || (p.sV & 7)) return LD_ERR_SHAPE;
+    // a row holds all H heads side by side (head h at columns h d .. h d + d - 1): a shorter row stride would make rows overlap / run off the end
+    const long long hd = (long long)p.H * p.d;
+    if (p.ldq < hd || p.ldk < hd || p.ldo < hd) return LD_ERR_SHAPE;
+    // batch strides of several images: an image's rows must not overlap the next image's
+    if (p.B > 1 && (p.sQ < (long long)(p.Lq - 1) * p.ldq + hd || p.sK < (long long)(p.Lk - 1) * p.ldk + hd || p.sO < (long long)(p.Lq - 1) * p.ldo + hd)) return LD_ERR_SHAPE;
     const int dk = (p.d + 15) / 16;
     if (p.V != nullptr) {   // row-major V (the UNet's fused q|k|v projection)
-        if ((p.ldv & 7) || p.ldv < p.d) return LD_ERR_SHAPE;
+        if ((p.ldv & 7) || p.ldv < hd) return LD_ERR_SHAPE;
+        if (p.B > 1 && p.sV < (long long)(p.Lk - 1) * p.ldv + hd) return LD_ERR_SHAPE;
         switch (dk) {
             case 1: launch_attn<1, true>(p, stream); break;
             case 2: launch_attn<2, true>(p, stream); break;

@@ -181,6 +181,36 @@ int ld_op_groupnorm_conv(const void* x1, int c1, const void* x2, int c2, int n, 
     return gemm_launch(p, stream);
 }
 
+size_t ld_op_conv_skip_ws_bytes(int c, int sc1, int sc2, int cout) {
+    return align256((size_t)cout * (9 * (size_t)c + sc1 + sc2) * sizeof(half_t)) + align256((size_t)cout * sizeof(half_t)) + ((size_t)96 << 20);
+}
+
+int ld_op_conv_skip(const void* x, int c, int n, int h, int w, const void* wt, const void* bias, const void* s1, int sc1, const void* s2, int sc2,
+                    const void* wskip, const void* bskip, const void* rowvec, void* y, int cout, void* ws, size_t ws_bytes, void* stream_) {
+    if (x == nullptr || wt == nullptr || bias == nullptr || s1 == nullptr || wskip == nullptr || bskip == nullptr || y == nullptr || ws == nullptr) return LD_ERR_ARG;
+    if (c <= 0 || sc1 <= 0 || sc2 < 0 || (sc2 > 0 && s2 == nullptr) || cout <= 0 || n <= 0 || h <= 0 || w <= 0) return LD_ERR_ARG;
+    if (ws_bytes < ld_op_conv_skip_ws_bytes(c, sc1, sc2, cout)) return LD_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int K9 = 9 * c, SC = sc1 + sc2;
+    char* q = (char*)ws;
+    half_t* wf = (half_t*)q; q += align256((size_t)cout * (K9 + SC) * sizeof(half_t));
+    half_t* bf = (half_t*)q; q += align256((size_t)cout * sizeof(half_t));
+    int st = skip_fold_launch((const half_t*)wt, (const half_t*)wskip, (const half_t*)bias, (const half_t*)bskip, cout, K9, SC, wf, bf, stream);
+    if (st != LD_OK) return st;
+    GemmParams p;
+    p.conv = 1; p.ksize = 3;
+    p.A = (const half_t*)x; p.C1 = c;
+    p.Hs = p.Hv = p.Ho = h; p.Ws = p.Wv = p.Wo = w; p.stride = 1;
+    p.S1 = (const half_t*)s1; p.SC1 = sc1; p.S2 = (const half_t*)s2; p.SC2 = sc2;
+    p.K = K9 + SC; p.W = wf; p.ldw = p.K;
+    p.M = n * h * w; p.N = cout;
+    p.bias_n = bf;
+    p.rowvec = (const half_t*)rowvec; p.rows_per_vec = h * w; p.ldrv = cout;
+    p.C = (half_t*)y; p.ldc = cout;
+    p.partial = (float*)q; p.partial_bytes = (size_t)96 << 20;
+    return gemm_launch(p, stream);
+}
+
 int ld_op_repack_conv(const void* src, int dtype, int cout, int cin, void* dst, void* stream) {
     return repack_conv3x3_launch(src, dtype == LD_F32, cout, cin, (half_t*)dst, (hipStream_t)stream);
 }
@@ -210,6 +240,12 @@ int ld_op_attention(const void* q, int ldq, const void* k, int ldk, const void* 
 
 int ld_op_attention_rowv(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int ldo, int b, int heads,
                          int lq, int lk, int d, float scale, int causal, void* stream) {
+    // q, k, v as column blocks of one fused [b][l][ldq] tensor (ldq == ldk == ldv with overlapping row ranges) share ONE batch stride,
+    // which the per-operand strides below only reproduce when lq == lk
+    const char *qb = (const char*)q, *kb = (const char*)k, *vb = (const char*)v;
+    const long long rowb = (long long)ldq * 2;
+    const bool fused = ldq == ldk && ldk == ldv && rowb > 0 && (kb - qb >= 0 ? kb - qb : qb - kb) < rowb && (vb - qb >= 0 ? vb - qb : qb - vb) < rowb;
+    if (fused && lq != lk) return LD_ERR_SHAPE;
     AttnParams a;
     a.Q = (const half_t*)q; a.ldq = ldq; a.sQ = (long long)lq * ldq;
     a.K = (const half_t*)k; a.ldk = ldk; a.sK = (long long)lk * ldk;

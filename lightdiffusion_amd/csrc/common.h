@@ -60,98 +60,92 @@ __device__ __forceinline__ uint4 add8h(uint4 a, uint4 b) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// exact (erf) GELU, as torch.nn.functional.gelu default used by the reference's GEGLU (LD.py:4513-4515)
+// exact (erf) GELU, as torch.nn.functional.gelu default used by the reference's GEGLU (LD.py:4513-4515):
+//   gelu(x) = x Phi(x) = max(x, 0) - |x| Phi(-|x|),   Phi(-z) = 2^P(z) on z = min(|x|, 6)
+// with P a degree-6 minimax fit of log2 Phi(-z) weighted for the absolute error of z Phi(-z) (tools/fit_gelu.py: max |error| 5.1e-7 over
+// [-12, 12] evaluated in fp32, relative 5e-5 where |gelu| > 1e-3 — the Abramowitz-Stegun 7.1.26 erf this replaces measured 6.8e-7 / 2.2e-4;
+// beyond z = 6 the true tail is < 6e-9).  ONE transcendental (v_exp_f32) and 10 single-issue fp32 operations per value instead of two
+// transcendentals + 12 packed-fp32 operations per PAIR: a v_pk_*_f32 beside MFMAs costs ~3x two scalar operations (microarch guide,
+// 'price of one filler beside MFMAs'), and the GEGLU epilogues are vector-issue bound (40 GELUs per lane and tile).
+#define LD_GELU_ZMAX 6.0f
+#define LD_GELU_C0 -0.999993086f
+#define LD_GELU_C1 -1.15120173f
+#define LD_GELU_C2 -0.458770961f
+#define LD_GELU_C3 -0.0534121096f
+#define LD_GELU_C4 0.00808071997f
+#define LD_GELU_C5 -0.000769220525f
+#define LD_GELU_C6 3.30928924e-05f
 __device__ __forceinline__ float gelu_f(float x) {
-    // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output step): one v_rcp + one v_exp + 6 FMA
-    // instead of libm erff's branchy ~30 instructions — the GEGLU epilogue runs this on 84M elements per level-0 block.
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-    const float erf_abs = 1.0f - poly * __expf(-z * z);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    const float z = fminf(fabsf(x), LD_GELU_ZMAX);
+    float q = fmaf(z, LD_GELU_C6, LD_GELU_C5);
+    q = fmaf(q, z, LD_GELU_C4);
+    q = fmaf(q, z, LD_GELU_C3);
+    q = fmaf(q, z, LD_GELU_C2);
+    q = fmaf(q, z, LD_GELU_C1);
+    q = fmaf(q, z, LD_GELU_C0);
+    return fmaf(-z, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));    // (q in [-30, -1]: never a denormal result)
 }
 
-// GEGLU products for 8 (value, gate) pairs: ow[k] = fp16x2( a * gelu(g) ) with the erf of gelu_f (Abramowitz-Stegun 7.1.26), written as
-// volatile asm STAGE BY STAGE over 4 register pairs: 4..8 independent instructions between a result and its use (no dependency or
-// transcendental-result bubbles), packed fp32 where the ISA has it, 12 instructions per product.  hipcc schedules the 40 independent GELUs
-// of a gate step chain by chain whatever the source order (and folds sched_barriers between pure operations): volatile asm keeps its order.
-// Measured in the row-panel GEMM's gate step: 5400 -> 5000 clocks.  What is left is the instruction mix itself — about 100 issue cycles per
-// product (2 transcendentals at quarter rate, 6 packed-fp32 operations at half rate) — not contention with the partner wave's MFMA stream:
-// idling that stream with s_nops leaves the 5000 clocks unchanged (profiles/README.md).
+// GEGLU products for 8 (value, gate) pairs: out = a * gelu(g) with the formula of gelu_f, written as volatile asm STAGE BY STAGE over the
+// 8 values: 7 independent instructions between a result and its use (no dependency or transcendental-result bubbles; the hazard
+// recogniser does not see inline asm).  hipcc schedules the 40 independent GELUs of a gate step chain by chain whatever the source order
+// (and folds sched_barriers between pure operations): volatile asm keeps its order.  Issue cost per value: 10 x 4 + 8 (v_exp_f32) + 2
+// (half a v_cvt_pk) = 50 cycles; round 4's packed form measured ~100 (profiles/README.md).
 // g: the 8 gates (fp32); values: aw (4 packed fp16 pairs) or af (fp32 pairs); results: ow (4 packed fp16 pairs) or of (fp32 pairs).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool APACKED, bool OPACKED>
 __device__ __forceinline__ void geglu8_staged_t(const unsigned (&aw)[4], const f32x2 (&af)[4], const f32x2 (&g)[4], unsigned (&ow)[4], f32x2 (&of)[4]) {
-    const f32x2 kP = {0.3275911f, 0.3275911f}, kL = {1.44269504088896340736f, 1.44269504088896340736f};
-    const f32x2 kA5 = {1.061405429f, 1.061405429f}, kA3 = {1.421413741f, 1.421413741f}, kA2 = {-0.284496736f, -0.284496736f},
-                kA1 = {0.254829592f, 0.254829592f};
-    f32x2 kA4 = {-1.453152027f, -1.453152027f};
-    asm volatile("" : "+v"(kA4));                 // lives in VGPRs: a VOP3P instruction takes one scalar operand
-    const float kC = 0.70710678118654752440f;
-    const unsigned kM = 0x7fffffffu;
-    f32x2 z[4], t[4], e[4], q[4], a[4];
-    asm volatile("s_nop 1");                       // (the inputs may come straight from packed-fp32 producers the asm reads are invisible to)
+    const float kZ = LD_GELU_ZMAX, k6 = LD_GELU_C6, k4 = LD_GELU_C4, k3 = LD_GELU_C3, k2 = LD_GELU_C2, k1 = LD_GELU_C1, k0 = LD_GELU_C0;
+    float k5 = LD_GELU_C5;
+    asm volatile("" : "+v"(k5));                  // lives in a VGPR: a VOP3 instruction reads one scalar operand
+    float gg[8], z[8], q[8], r[8], a[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                  // z = |g| / sqrt(2)
-        asm volatile("v_mul_f32 %0, |%1|, %2" : "=v"(z[k].x) : "v"(g[k].x), "s"(kC));
-        asm volatile("v_mul_f32 %0, |%1|, %2" : "=v"(z[k].y) : "v"(g[k].y), "s"(kC));
+    for (int k = 0; k < 4; ++k) {
+        gg[2 * k] = g[k].x;
+        gg[2 * k + 1] = g[k].y;
     }
+    asm volatile("s_nop 1");                       // (the inputs may come straight from producers the asm reads are invisible to)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel_hi:[1,1,0]" : "=v"(t[k]) : "v"(z[k]), "s"(kP));   // 1 + p z
+    for (int e = 0; e < 8; ++e) asm volatile("v_min_f32 %0, |%1|, %2" : "=v"(z[e]) : "v"(gg[e]), "s"(kZ));                 // z = min(|g|, 6)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_pk_mul_f32 %0, %1, %1 neg_lo:[1,0] neg_hi:[1,0]" : "=v"(e[k]) : "v"(z[k]));         // -z^2
+    for (int e = 0; e < 8; ++e) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q[e]) : "v"(z[e]), "s"(k6), "v"(k5));       // Horner in z
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                  // t = 1 / (1 + p z)
-        asm volatile("v_rcp_f32 %0, %0" : "+v"(t[k].x));
-        asm volatile("v_rcp_f32 %0, %0" : "+v"(t[k].y));
-    }
+    for (int e = 0; e < 8; ++e) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(q[e]) : "v"(z[e]), "s"(k4));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(e[k]) : "s"(kL));
+    for (int e = 0; e < 8; ++e) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(q[e]) : "v"(z[e]), "s"(k3));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                  // e = exp(-z^2)
-        asm volatile("v_exp_f32 %0, %0" : "+v"(e[k].x));
-        asm volatile("v_exp_f32 %0, %0" : "+v"(e[k].y));
-    }
+    for (int e = 0; e < 8; ++e) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(q[e]) : "v"(z[e]), "s"(k2));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(q[k]) : "v"(t[k]), "s"(kA5), "v"(kA4));           // Horner in t
+    for (int e = 0; e < 8; ++e) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(q[e]) : "v"(z[e]), "s"(k1));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(q[k]) : "v"(t[k]), "s"(kA3));
+    for (int e = 0; e < 8; ++e) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(q[e]) : "v"(z[e]), "s"(k0));
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(q[k]) : "v"(t[k]), "s"(kA2));
+    for (int e = 0; e < 8; ++e) asm volatile("v_exp_f32 %0, %0" : "+v"(q[e]));                                             // Phi(-z)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(q[k]) : "v"(t[k]), "s"(kA1));
-#pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(q[k]) : "v"(t[k]));
-#pragma unroll
-    for (int k = 0; k < 4; ++k)                    // erf(|z|) = 1 - poly * e
-        asm volatile("v_pk_fma_f32 %0, %0, %1, 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(q[k]) : "v"(e[k]));
+    for (int e = 0; e < 8; ++e) asm volatile("v_max_f32 %0, 0, %1" : "=v"(r[e]) : "v"(gg[e]));                             // max(g, 0)
     if (APACKED) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {              // the value halves, to fp32
-            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(a[k].x) : "v"(aw[k]));
-            asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(a[k].y) : "v"(aw[k]));
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(a[2 * k]) : "v"(aw[k]));
+            asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(a[2 * k + 1]) : "v"(aw[k]));
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = af[k];
+        for (int k = 0; k < 4; ++k) {
+            a[2 * k] = af[k].x;
+            a[2 * k + 1] = af[k].y;
+        }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                  // copysign(erf, g)
-        asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(q[k].x) : "s"(kM), "v"(g[k].x));
-        asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(q[k].y) : "s"(kM), "v"(g[k].y));
-    }
+    for (int e = 0; e < 8; ++e) asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(r[e]) : "v"(z[e]), "v"(q[e]));             // gelu = max(g, 0) - z Phi(-z)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_pk_mul_f32 %0, %1, 0.5 op_sel_hi:[1,0]" : "=v"(t[k]) : "v"(g[k]));                   // g / 2
-#pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_pk_fma_f32 %0, %1, %0, %1" : "+v"(q[k]) : "v"(t[k]));                                // gelu = g/2 * erf + g/2
-#pragma unroll
-    for (int k = 0; k < 4; ++k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(q[k]) : "v"(a[k]));
+    for (int e = 0; e < 8; ++e) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(r[e]) : "v"(a[e]));
     if (OPACKED) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ow[k]) : "v"(q[k].x), "v"(q[k].y));
+        for (int k = 0; k < 4; ++k) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ow[k]) : "v"(r[2 * k]), "v"(r[2 * k + 1]));
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) of[k] = q[k];
+        for (int k = 0; k < 4; ++k) of[k] = (f32x2){r[2 * k], r[2 * k + 1]};
     }
 }
 __device__ __forceinline__ void geglu8_staged(const unsigned (&aw)[4], const f32x2 (&g)[4], unsigned (&ow)[4]) {

@@ -32,6 +32,7 @@
 // One launch replaces conv + split-K reduce (+ gn_stats of the next norm).  Small patches keep S small: the fp32 slabs
 // (S x M x N x 4 bytes, written and read once) were the largest cost of a first version with 512-row tiles (S = 16: 84 MB per launch).
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "gemm.h"
@@ -517,7 +518,20 @@ __global__ __launch_bounds__(C8_THREADS, 3) void conv8_kernel(const GemmParams p
 #pragma unroll
             for (int q2 = 0; q2 < NL; ++q2) x[u][q2] = ld16_sc1(base + (long long)(SS ? q2 : (q2 < S ? q2 : S - 1)) * slab_stride);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the asm loads above are untracked (DESIGN "hipcc traps" (c)): the wait names every destination register as an in/out operand, so
+        // no copy, spill or reuse of x can be scheduled between a load and the wait (one wait statement per item: <= 16 operands each)
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            if constexpr (NL == 16)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[u][0]), "+v"(x[u][1]), "+v"(x[u][2]), "+v"(x[u][3]), "+v"(x[u][4]), "+v"(x[u][5]), "+v"(x[u][6]), "+v"(x[u][7]),
+                             "+v"(x[u][8]), "+v"(x[u][9]), "+v"(x[u][10]), "+v"(x[u][11]), "+v"(x[u][12]), "+v"(x[u][13]), "+v"(x[u][14]), "+v"(x[u][15])::"memory");
+            else if constexpr (NL == 8)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[u][0]), "+v"(x[u][1]), "+v"(x[u][2]), "+v"(x[u][3]), "+v"(x[u][4]), "+v"(x[u][5]), "+v"(x[u][6]), "+v"(x[u][7])::"memory");
+            else if constexpr (NL == 4)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[u][0]), "+v"(x[u][1]), "+v"(x[u][2]), "+v"(x[u][3])::"memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[u][0]), "+v"(x[u][1])::"memory");
+        }
         __builtin_amdgcn_sched_barrier(0);                      // (nothing that reads x moves above the wait)
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
@@ -576,22 +590,28 @@ constexpr int c8_lds_bytes() {
 }
 
 template <int WD, bool UP>
-void c8_launch(const GemmParams& p, hipStream_t stream) {
+int c8_launch(const GemmParams& p, hipStream_t stream) {
     constexpr int lds = c8_lds_bytes<WD>();
     static_assert(lds <= 163840, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8_kernel<WD, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
+    // > 64 KB of dynamic LDS needs the attribute on EVERY device the kernel is launched on: one once_flag per device (thread-safe), and a
+    // failed call is reported (the launch itself would only fail later, as LD_ERR_HIP)
+    constexpr int MAXDEV = 64;
+    static std::once_flag once[MAXDEV];
+    static bool ok[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return LD_ERR_HIP;
+    std::call_once(once[dev], [&] {
+        ok[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8_kernel<WD, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    });
+    if (!ok[dev]) return LD_ERR_HIP;
     const int groups = (p.N / C8_BN) * p.c8_S, tms = p.M / 128;
     hipLaunchKernelGGL((conv8_kernel<WD, UP>), dim3((unsigned)(groups * tms)), dim3(C8_THREADS), lds, stream, p);
+    return LD_OK;
 }
 
 template <int WD>
-void c8_dispatch(const GemmParams& p, hipStream_t stream) {
-    if (p.Hv == 2 * p.Hs) c8_launch<WD, true>(p, stream);
-    else c8_launch<WD, false>(p, stream);
+int c8_dispatch(const GemmParams& p, hipStream_t stream) {
+    return p.Hv == 2 * p.Hs ? c8_launch<WD, true>(p, stream) : c8_launch<WD, false>(p, stream);
 }
 
 // [O][tap][I] (the general layout, ld_op_repack_conv / PK_CONV3) -> conv8's stage images: chunk (j, ss, t, n, pc) of 8 halfs holds
@@ -631,7 +651,7 @@ bool conv8_plan(const GemmParams& p, int* S_out) {
           p.bm == 0 && p.bn == 0 && p.splitk == 0 && p.W8 != nullptr && p.partial != nullptr && p.sync != nullptr && p.stat_out == nullptr && p.ln_stat == nullptr))
         return false;
     const bool same = p.Hv == p.Hs && p.Wv == p.Ws;
-    if (p.gn_scale != nullptr) return false;                                            // (this kernel takes the normalised tensor)
+    if (p.gn_scale != nullptr || p.SC1 > 0) return false;                               // (this kernel takes the normalised tensor; no second K segment)
     const bool up = p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws && p.C2 == 0;
     if (!(same || up) || p.Ho != p.Hv || p.Wo != p.Wv || p.Ho != p.Wo) return false;
     if (!(p.Wo == 8 || p.Wo == 16 || p.Wo == 32 || p.Wo == 64) || p.M % 128 || p.M % (p.Wo * p.Wo)) return false;
@@ -642,7 +662,9 @@ bool conv8_plan(const GemmParams& p, int* S_out) {
     if (p.n_valid > 0 && p.n_valid < p.N) return false;
     const int Cin = p.C1 + p.C2, nsub = Cin / 16, ntn = p.N / C8_BN, tms = p.M / 128;
     if (p.K != 9 * Cin) return false;
-    if (p.gn_part != nullptr && ((p.N / 32) & 1)) return false;
+    // GroupNorm partials of the output: part_stats assumes every 80-column N tile holds WHOLE groups (80 % (N / 32) == 0: N = 320, 640, 1280 ..;
+    // N = 960 / 1600 / 1920 would split groups over tiles) of an even number of channels (a float4 item carries channel PAIRS)
+    if (p.gn_part != nullptr && ((p.N % 32) || ((p.N / 32) & 1) || (C8_BN % (p.N / 32)))) return false;
     // the patches x N tiles must leave room for a split that fills the chip, and the split must keep the weight stream worth it
     const long long tiles = (long long)tms * ntn;
     if (tiles > 256 || tiles * 4 > LD_SYNC_INTS) return false;
@@ -680,11 +702,13 @@ int conv8_launch(const GemmParams& pin, hipStream_t stream) {
         if (p.rowvec == nullptr) { p.rowvec = zero_page; p.ldrv = 0; p.rows_per_vec = 1; }
         if (p.R == nullptr) { p.R = zero_page; p.ldr = 0; }
     }
+    int st;
     switch (p.Wo) {
-        case 8: c8_dispatch<8>(p, stream); break;
-        case 16: c8_dispatch<16>(p, stream); break;
-        case 32: c8_dispatch<32>(p, stream); break;
-        default: c8_dispatch<64>(p, stream); break;
+        case 8: st = c8_dispatch<8>(p, stream); break;
+        case 16: st = c8_dispatch<16>(p, stream); break;
+        case 32: st = c8_dispatch<32>(p, stream); break;
+        default: st = c8_dispatch<64>(p, stream); break;
     }
+    if (st != LD_OK) return st;
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }

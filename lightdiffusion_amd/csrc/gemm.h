@@ -16,6 +16,13 @@ struct GemmParams {
     int Hv = 0, Wv = 0;          // size the conv sees (after nearest resize; == Hs,Ws without upsample)
     int Ho = 0, Wo = 0, stride = 1;
     int C1 = 0, C2 = 0;
+    // ---- second K segment of a convolution (tap-major kernels): a 1x1 convolution over up to two RAW NHWC sources of the OUTPUT's spatial
+    //   size, appended to the K axis — K = ksize^2 (C1 + C2) + SC1 + SC2, weight rows [conv taps | skip channels].  ResBlock1's
+    //   skip_connection folded into out_layers' convolution (LD.py:5267, 5273-5287): out = W2 * gn(h) + Wskip x + (b2 + bskip) is ONE
+    //   contraction; requires stride 1 and no resize.  The halo-tile and row-resident kernels decline it (gemm_conv_takes_skip_segment).
+    const half_t* S1 = nullptr;
+    const half_t* S2 = nullptr;
+    int SC1 = 0, SC2 = 0;
     // ---- B operand (weights [N][K], K contiguous)
     const half_t* W = nullptr;
     int ldw = 0;
@@ -97,5 +104,8 @@ int gemm_launch(const GemmParams& p, hipStream_t stream);
 // true when gemm_launch would run this convolution on the halo-tile kernel, i.e. when it can take gn_scale / gn_shift
 // (fill every other field first; gemm_launch rejects gn_scale on any other path)
 bool gemm_conv_fuses_groupnorm(const GemmParams& p);
+// does gemm_launch run this 3x3 convolution on a kernel that walks K tap-major (the 128 x 160 / 256 x 320 implicit-GEMM kernels), i.e. one
+// that can take a second K segment (S1 / S2)?  Fill every field (partial, sync, W8 included) as for the launch itself, without the segment.
+bool gemm_conv_takes_skip_segment(const GemmParams& p);
 // does gemm_launch run this convolution on the halo-tile kernel?  (callers that need a property of it: the VAE's MFMA output conv)
 bool gemm_conv_takes_halo_tile(const GemmParams& p);

@@ -437,18 +437,22 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
     const half_t* a_base = Ab + (long long)kt_begin * BK3;   // wave-uniform
     int seg_left = 0;
     auto conv_seek = [&](int k0) {
-        const int tap = k0 / Cin;
-        const int c0 = k0 - tap * Cin;
-        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
-        const bool second = c0 >= p.C1;
-        const half_t* src = second ? p.A2 : Ab;
-        const int Cs = second ? p.C2 : p.C1;
-        const int cl = second ? c0 - p.C1 : c0;
-        seg_left = ((second ? Cin : p.C1) - c0) / BK3;
+        // (k0 beyond the taps: the second K segment — the 1x1 skip convolution's raw sources at the output pixel itself, gemm.h S1 / S2)
+        const int K9 = p.ksize * p.ksize * Cin;
+        const bool skp = k0 >= K9 && p.SC1 > 0;
+        const int tap = skp ? 0 : k0 / Cin;
+        const int c0 = skp ? k0 - K9 : k0 - tap * Cin;
+        const int ky = skp ? p.pad : tap / p.ksize, kx = skp ? p.pad : tap - (tap / p.ksize) * p.ksize;
+        const int Ca = skp ? p.SC1 : p.C1, Cb = skp ? p.SC2 : p.C2;
+        const bool second = c0 >= Ca;
+        const half_t* src = skp ? (second ? p.S2 : p.S1) : (second ? p.A2 : Ab);
+        const int Cs = second ? Cb : Ca;
+        const int cl = second ? c0 - Ca : c0;
+        seg_left = ((second ? Ca + Cb : Ca) - c0) / BK3;
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv && tap < p.ksize * p.ksize;
+            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv && tap < p.ksize * p.ksize && c0 < Ca + Cb;
             int sy = iy, sx = ix;
             if (p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws) {
                 sy = iy >> 1;
@@ -707,18 +711,22 @@ __global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
         const half_t* a_base = Ab + (long long)kt_begin * BK3;
         int seg_left = 0;
         auto conv_seek = [&](int k0) {
-            const int tap = k0 / Cin;
-            const int c0 = k0 - tap * Cin;
-            const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
-            const bool second = c0 >= p.C1;
-            const half_t* src = second ? p.A2 : Ab;
-            const int Cs = second ? p.C2 : p.C1;
-            const int cl = second ? c0 - p.C1 : c0;
-            seg_left = ((second ? Cin : p.C1) - c0) / BK3;
+            // (k0 beyond the taps: the second K segment — the 1x1 skip convolution's raw sources at the output pixel itself, gemm.h S1 / S2)
+            const int K9 = p.ksize * p.ksize * Cin;
+            const bool skp = k0 >= K9 && p.SC1 > 0;
+            const int tap = skp ? 0 : k0 / Cin;
+            const int c0 = skp ? k0 - K9 : k0 - tap * Cin;
+            const int ky = skp ? p.pad : tap / p.ksize, kx = skp ? p.pad : tap - (tap / p.ksize) * p.ksize;
+            const int Ca = skp ? p.SC1 : p.C1, Cb = skp ? p.SC2 : p.C2;
+            const bool second = c0 >= Ca;
+            const half_t* src = skp ? (second ? p.S2 : p.S1) : (second ? p.A2 : Ab);
+            const int Cs = second ? Cb : Ca;
+            const int cl = second ? c0 - Ca : c0;
+            seg_left = ((second ? Ca + Cb : Ca) - c0) / BK3;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
-                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv && tap < p.ksize * p.ksize;
+                const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv && tap < p.ksize * p.ksize && c0 < Ca + Cb;
                 int sy = iy, sx = ix;
                 if (p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws) {
                     sy = iy >> 1;
@@ -1352,14 +1360,18 @@ __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
     int seg_left = 0;
     int k_issue = kt_begin * V5_BK;                                 // K index of the next step to issue
     auto conv_seek = [&](int k0) {
-        const int tap = k0 / Cin;
-        const int c0 = k0 - tap * Cin;
-        const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
-        const bool second = c0 >= p.C1;
-        const half_t* src = second ? p.A2 : Ab;
-        const int Cs = second ? p.C2 : p.C1;
-        const int cl = second ? c0 - p.C1 : c0;
-        seg_left = ((second ? Cin : p.C1) - c0) / V5_BK;
+        // (k0 beyond the taps: the second K segment — the 1x1 skip convolution's raw sources at the output pixel itself, gemm.h S1 / S2)
+        const int K9 = p.ksize * p.ksize * Cin;
+        const bool skp = k0 >= K9 && p.SC1 > 0;
+        const int tap = skp ? 0 : k0 / Cin;
+        const int c0 = skp ? k0 - K9 : k0 - tap * Cin;
+        const int ky = skp ? p.pad : tap / p.ksize, kx = skp ? p.pad : tap - (tap / p.ksize) * p.ksize;
+        const int Ca = skp ? p.SC1 : p.C1, Cb = skp ? p.SC2 : p.C2;
+        const bool second = c0 >= Ca;
+        const half_t* src = skp ? (second ? p.S2 : p.S1) : (second ? p.A2 : Ab);
+        const int Cs = second ? Cb : Ca;
+        const int cl = second ? c0 - Ca : c0;
+        seg_left = ((second ? Ca + Cb : Ca) - c0) / V5_BK;
         const int hw = p.Ho * p.Wo;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1368,7 +1380,7 @@ __global__ __launch_bounds__(512, 2) void gemm5_kernel(const GemmParams p) {
             const int img = mm / hw, rem = mm - img * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
-            const bool ok = m < p.M && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv && tap < p.ksize * p.ksize;
+            const bool ok = m < p.M && (unsigned)iy < (unsigned)p.Hv && (unsigned)ix < (unsigned)p.Wv && tap < p.ksize * p.ksize && c0 < Ca + Cb;
             int sy = iy, sx = ix;
             if (p.Hv == 2 * p.Hs && p.Wv == 2 * p.Ws) {
                 sy = iy >> 1;
@@ -2406,6 +2418,7 @@ static bool v6_plan(const GemmParams& p, V6Plan* out) {
           p.C1 % 32 == 0 && p.C2 % 32 == 0 && p.bm == 0 && p.bn == 0 && p.splitk == 0 && p.batch == 1 && p.act != 2))
         return false;
     if (up && (p.C2 != 0 || p.gn_scale != nullptr)) return false;
+    if (p.SC1 > 0) return false;                                     // (a second K segment: the tap-major kernels)
     const int wc = (p.Wo == 16 || p.Wo == 32 || p.Wo == 64 || p.Wo == 128) ? p.Wo : (p.Wo > 128 && p.Wo % 128 == 0) ? 128 : 0;
     if (wc == 0) return false;
 #ifdef LD_AB_BUILD
@@ -2463,6 +2476,11 @@ static bool v6_plan(const GemmParams& p, V6Plan* out) {
     return t6 * sk6 >= 192;
 }
 
+bool gemm_conv_takes_skip_segment(const GemmParams& p) {
+    V6Plan pl;
+    return p.conv && p.ksize == 3 && p.stride == 1 && p.Hv == p.Hs && p.Wv == p.Ws && p.SC1 == 0 && !conv8_plan(p, nullptr) && !v6_plan(p, &pl);
+}
+
 bool gemm_conv_takes_halo_tile(const GemmParams& pin) {
     GemmParams p = pin;
     V6Plan pl;
@@ -2497,7 +2515,12 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         const int Cin = p.C1 + p.C2;
         if (p.ksize != 1 && p.ksize != 3) return LD_ERR_ARG;
         if (p.pad < 0) p.pad = p.ksize >> 1;
-        if (Cin <= 0 || (p.C1 % 64) || (p.C2 % 64) || p.K != p.ksize * p.ksize * Cin) return LD_ERR_SHAPE;
+        if (p.SC1 < 0 || p.SC2 < 0 || (p.SC1 == 0 && p.SC2 != 0)) return LD_ERR_ARG;
+        if (Cin <= 0 || (p.C1 % 64) || (p.C2 % 64) || (p.SC1 % 64) || (p.SC2 % 64) || p.K != p.ksize * p.ksize * Cin + p.SC1 + p.SC2) return LD_ERR_SHAPE;
+        if (p.SC1 > 0) {   // second K segment (gemm.h): raw sources of the output's size, read at the output pixel itself
+            if (p.S1 == nullptr || (p.SC2 > 0 && p.S2 == nullptr)) return LD_ERR_ARG;
+            if (p.stride != 1 || p.Hv != p.Hs || p.Wv != p.Ws || p.Ho != p.Hv || p.Wo != p.Wv || p.pad != p.ksize / 2 || p.SC1 > 32768 || p.SC2 > 32768) return LD_ERR_SHAPE;
+        }
         if (p.C1 > 32768 || p.C2 > 32768) return LD_ERR_SHAPE;   // the stepped zero row (g_zero_row) covers one tap's channel run
         if (p.C2 > 0 && p.A2 == nullptr) return LD_ERR_ARG;
         if (p.M % (p.Ho * p.Wo)) return LD_ERR_SHAPE;

@@ -54,6 +54,9 @@ int ln_fold_launch(const half_t* W, int N, int K, const half_t* gamma, const hal
                    float* wsum, hipStream_t stream);
 // W'[C][5C] = [Wpo W2 | Wpo], b' = Wpo b2 + bpo (ff.net.2 followed by proj_out as one contraction; see misc.hip)
 int mlp_out_fold_launch(const half_t* Wpo, const half_t* W2, const half_t* b2, const half_t* bpo, int C, half_t* Wout, half_t* bout, hipStream_t stream);
+// W'[N][K9 + SC] = [W2 | Wsk], b' = b2 + bsk (a ResBlock's skip_connection as a second K segment of its out_layers convolution; see misc.hip)
+int skip_fold_launch(const half_t* W2, const half_t* Wsk, const half_t* b2, const half_t* bsk, int N, int K9, int SC, half_t* Wout, half_t* bout,
+                     hipStream_t stream);
 struct SmallConvInArgs {        // 3x3 pad-1 conv with <= 4 input channels from an fp32 NCHW tensor (conv_in of UNet / VAE)
     const float* x = nullptr;   // [N][Cin][H][W] fp32
     const float* scale_sigma = nullptr;  // optional [N]: input scaled by 1/sqrt(sigma^2+1) (EPS.calculate_input, LD.py:1259-1261)

@@ -546,3 +546,35 @@ int mlp_out_fold_launch(const half_t* Wpo, const half_t* W2, const half_t* b2, c
     hipLaunchKernelGGL(mlp_out_fold_kernel, dim3(C), dim3(256), (size_t)C * sizeof(float), stream, Wpo, W2, b2, bpo, C, Wout, bout);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Skip fold (unet.hip): ResBlock1 with a 1x1 skip_connection computes  out = conv3x3(h; W2) + b2 + conv1x1(x; Wsk) + bsk  (LD.py:5267,
+// 5273-5287) — one contraction over K = 9 Cout + Cin with the skip sources as a second K segment (gemm.h S1 / S2).  This kernel derives
+// W'[n] = [W2[n][tap][c] | Wsk[n][:]] and b' = b2 + bsk (fp32 sum, one rounding) once per weight load.
+namespace {
+__global__ __launch_bounds__(256) void skip_fold_kernel(const uint4* __restrict__ W2, const uint4* __restrict__ Wsk, const half_t* __restrict__ b2,
+                                                        const half_t* __restrict__ bsk, int N, int K9c, int SCc, uint4* __restrict__ Wout, half_t* __restrict__ bout) {
+    const int Kc = K9c + SCc;                     // 16-byte chunks per output row
+    const long long total = (long long)N * Kc;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(q / Kc), c = (int)(q - (long long)n * Kc);
+        Wout[q] = c < K9c ? W2[(long long)n * K9c + c] : Wsk[(long long)n * SCc + (c - K9c)];
+    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < N) bout[t] = (half_t)((float)b2[t] + (float)bsk[t]);
+}
+}  // namespace
+
+int skip_fold_launch(const half_t* W2, const half_t* Wsk, const half_t* b2, const half_t* bsk, int N, int K9, int SC, half_t* Wout, half_t* bout,
+                     hipStream_t stream) {
+    if (W2 == nullptr || Wsk == nullptr || b2 == nullptr || bsk == nullptr || Wout == nullptr || bout == nullptr || N <= 0 || K9 <= 0 || SC <= 0 ||
+        (K9 & 7) || (SC & 7))
+        return LD_ERR_ARG;
+    const long long total = (long long)N * ((K9 + SC) / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks * 256 < N) blocks = (N + 255) / 256;
+    hipLaunchKernelGGL(skip_fold_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const uint4*>(W2), reinterpret_cast<const uint4*>(Wsk), b2, bsk, N,
+                       K9 / 8, SC / 8, reinterpret_cast<uint4*>(Wout), bout);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}

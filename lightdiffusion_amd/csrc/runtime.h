@@ -233,6 +233,14 @@ struct Exec {
         note(gemm_launch(p, stream));
         t_end(gemm_last_kernel_name());
     }
+    // would gemm() run this 3x3 convolution on a kernel that takes a second K segment (gemm.h S1 / S2)?
+    bool conv_takes_skip_segment(GemmParams p) const {
+        p.partial = splitk_ws;
+        p.partial_bytes = splitk_bytes;
+        p.sync = sync_ws;
+        if (ab_flags & 4) p.W8 = nullptr;
+        return gemm_conv_takes_skip_segment(p);
+    }
     // `ready` / `ready_P`: partial statistics the producer already wrote (gemm.h gn_part; ready_P pixel chunks per image): the statistics
     // launch is skipped
     void groupnorm(const half_t* x1, int C1, const half_t* x2, int C2, int n, int HW, const half_t* g, const half_t* b, float eps,

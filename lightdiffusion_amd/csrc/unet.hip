@@ -20,6 +20,9 @@ struct ResW {
     std::string prefix;
     int cin = 0, cout = 0, emb_off = 0;
     int gn1_g, gn1_b, c1_w, c1_b, emb_w, emb_b, gn2_g, gn2_b, c2_w, c2_b, sk_w = -1, sk_b = -1;
+    // skip fold (derived with the LayerNorm folds): [W2 | Wskip] ([cout][9 cout + cin]) and b2 + bskip — the 1x1 skip_connection runs as a
+    // second K segment of out_layers' convolution where that convolution runs on a tap-major kernel (gemm.h S1 / S2); byte offsets into fold_base
+    size_t f_c2_w = 0, f_c2_b = 0;
 };
 struct StW {
     int c = 0, bn = 0, ctx_slot = 0;
@@ -123,6 +126,11 @@ int add_res(ld_unet* u, const std::string& p, int cin, int cout) {
     if (cin != cout) {
         r.sk_w = t.add(p + ".skip_connection.weight", PK_MAT, {cout, cin, 1, 1});
         r.sk_b = t.add(p + ".skip_connection.bias", PK_VEC, {cout});
+        size_t& fb = u->fold_bytes;
+        r.f_c2_w = fb;
+        fb += ((size_t)cout * (9 * cout + cin) * sizeof(half_t) + 255) / 256 * 256;
+        r.f_c2_b = fb;
+        fb += ((size_t)cout * sizeof(half_t) + 255) / 256 * 256;
     }
     r.emb_off = u->emb_total;
     u->emb_total += cout;
@@ -374,13 +382,32 @@ struct Run {
         half_t* g2 = g1;   // g1 is dead once conv1 has consumed it (stream order); reuse when it is large enough
         if (r.cout > r.cin) g2 = ar.halfs(M * r.cout);
         const half_t* skip = x1;
+        bool fold_skip = false;
         if (r.sk_w >= 0) {
-            half_t* sk = ar.halfs(M * r.cout);
-            conv3(x1, C1, x2, C2, H, W, H, W, 1, r.sk_w, r.sk_b, r.cout, nullptr, 0, nullptr, sk, nullptr, nullptr, 1);
-            skip = sk;
+            // the 1x1 skip_connection: a second K segment of out_layers' convolution (same FLOPs at the 3x3 kernels' rate, one launch and one
+            // [M][cout] round trip less) where that convolution runs on a tap-major kernel; a separate launch in front of the halo-tile and
+            // row-resident kernels
+            GemmParams probe = conv_params(h1, r.cout, nullptr, 0, r.c2_w, r.c2_b, nullptr, 0, nullptr, out);
+            fold_skip = u->ln_fold && u->fold_base != nullptr && ex.conv_takes_skip_segment(probe);
+#ifdef LD_AB_BUILD
+            if (g_unet_dbg & 8) fold_skip = false;
+#endif
+            half_t* sk = (!fold_skip || ex.dry) ? ar.halfs(M * r.cout) : nullptr;   // (a planning run sizes for either route: ld_unet_reserve plans before the split-K scratch exists)
+            if (!fold_skip) {
+                conv3(x1, C1, x2, C2, H, W, H, W, 1, r.sk_w, r.sk_b, r.cout, nullptr, 0, nullptr, sk, nullptr, nullptr, 1);
+                skip = sk;
+            }
         }
         {
             GemmParams c2 = conv_params(h1, r.cout, nullptr, 0, r.c2_w, r.c2_b, nullptr, 0, skip, out);
+            if (fold_skip) {
+                c2.S1 = x1; c2.SC1 = C1; c2.S2 = x2; c2.SC2 = C2;
+                c2.W = reinterpret_cast<const half_t*>(u->fold_base + r.f_c2_w);
+                c2.K = 9 * r.cout + r.cin; c2.ldw = c2.K;
+                c2.bias_n = reinterpret_cast<const half_t*>(u->fold_base + r.f_c2_b);
+                c2.R = nullptr;
+                c2.W8 = nullptr;
+            }
             want_stats(c2, gno, H * W, &gno_done);
             ex.gn_silu_conv(c2, n, H * W, P(r.gn2_g), P(r.gn2_b), 1e-5f, g2, gnp_done ? gnp : nullptr, gnp_done);
         }
@@ -553,6 +580,12 @@ int fold_layernorms(ld_unet* u, hipStream_t stream) {
         if (st == LD_OK) st = ln_fold_launch(u->pt.ptr(s.q2_w), C, C, u->pt.ptr(s.ln2_g), u->pt.ptr(s.ln2_b), nullptr, H(s.f_q2_w), H(s.f_q2_b), F(s.f_q2_s), stream);
         if (st == LD_OK) st = ln_fold_launch(u->pt.ptr(s.ff1_w), 8 * C, C, u->pt.ptr(s.ln3_g), u->pt.ptr(s.ln3_b), u->pt.ptr(s.ff1_b), H(s.f_ff1_w), H(s.f_ff1_b), F(s.f_ff1_s), stream);
         if (st == LD_OK) st = mlp_out_fold_launch(u->pt.ptr(s.pout_w), u->pt.ptr(s.ff2_w), u->pt.ptr(s.ff2_b), u->pt.ptr(s.pout_b), C, H(s.f_mo_w), H(s.f_mo_b), stream);
+        if (st != LD_OK) return st;
+    }
+    for (const ResW& r : u->res) {
+        if (r.sk_w < 0) continue;
+        const int st = skip_fold_launch(u->pt.ptr(r.c2_w), u->pt.ptr(r.sk_w), u->pt.ptr(r.c2_b), u->pt.ptr(r.sk_b), r.cout, 9 * r.cout, r.cin,
+                                        reinterpret_cast<half_t*>(u->fold_base + r.f_c2_w), reinterpret_cast<half_t*>(u->fold_base + r.f_c2_b), stream);
         if (st != LD_OK) return st;
     }
     u->fold_dirty = false;

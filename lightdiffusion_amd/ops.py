@@ -121,6 +121,22 @@ def conv2d(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor]
     return y
 
 
+def conv2d_skip(x: torch.Tensor, w_packed: torch.Tensor, bias: torch.Tensor, s1: torch.Tensor, s2: Optional[torch.Tensor], w_skip: torch.Tensor,
+                b_skip: torch.Tensor, rowvec: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ResBlock1's out_layers convolution + its 1x1 skip_connection as one contraction (LD.py:5267, 5273-5287):
+    y = conv3x3(x; w_packed) + bias + conv1x1(cat(s1, s2); w_skip) + b_skip.  x [N,H,W,C]; s1 / s2 raw NHWC sources of the same H x W;
+    w_skip [Cout, C(s1) + C(s2)] (the checkpoint's [O, I, 1, 1] reshaped)."""
+    n, h, w, c = x.shape
+    sc1 = s1.shape[-1]
+    sc2 = 0 if s2 is None else s2.shape[-1]
+    cout = w_packed.shape[0]
+    y = torch.empty(n, h, w, cout, dtype=torch.float16, device=x.device)
+    ws = _ws(lib().ld_op_conv_skip_ws_bytes(c, sc1, sc2, cout), x.device)
+    check(lib().ld_op_conv_skip(_p(x), c, n, h, w, _p(w_packed), _p(bias), _p(s1), sc1, _p(s2), sc2, _p(w_skip), _p(b_skip), _p(rowvec), _p(y), cout,
+                                _p(ws), ws.numel(), _stream()), "ld_op_conv_skip")
+    return y
+
+
 def conv2d_gn_partials(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], out_hw: Optional[tuple] = None,
                        residual: Optional[torch.Tensor] = None):
     """3x3 stride-1 NHWC conv that also returns the GroupNorm(32) partial statistics its kernel wrote for the OUTPUT:

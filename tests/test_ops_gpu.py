@@ -171,7 +171,7 @@ def test_attention(ops, b, heads, lq, lk, d):
     (2, 8, 256, 256, 40), (1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160), (2, 8, 64, 64, 160),
     (2, 8, 100, 77, 40), (2, 8, 1024, 77, 80), (1, 8, 64, 77, 160), (2, 8, 192, 192, 8), (1, 4, 130, 200, 32), (2, 2, 70, 154, 64),
     (2, 2, 200, 130, 96), (1, 2, 128, 192, 128), (1, 3, 90, 90, 16), (8, 8, 2304, 2304, 40), (8, 8, 2200, 2200, 40),
-    (8, 8, 2112, 2112, 40), (8, 8, 2176, 2176, 40), (8, 8, 2240, 2240, 40), (16, 8, 4096, 4096, 40)])   # the pipelined d = 40 kernel: 33 / 34 / 35 / 64 key tiles (ring of four)
+    (8, 8, 2112, 2112, 40), (8, 8, 2176, 2176, 40), (8, 8, 2240, 2240, 40), (16, 8, 4096, 4096, 40)])   # 33 / 34 / 35 / 64 key tiles of the 8-wave variant (an odd / even count of double-buffer flips, a ragged last tile)
 def test_attention_row_major_v(ops, b, heads, lq, lk, d):
     c = heads * d
     q, k, v = r16((b, lq, c), 51), r16((b, lk, c), 52), r16((b, lk, c), 53)
@@ -183,9 +183,9 @@ def test_attention_row_major_v(ops, b, heads, lq, lk, d):
         assert rel_l2(y.float().cpu(), ref) < TOL
 
 
-def test_attention_pipelined_rescale_branch(ops):
-    """The pipelined d = 40 kernel (flash_attn3_kernel) when the softmax reference moves late: a few keys far larger than the rest in late
-    tiles, for some queries only — S^T of the next unit, O^T and the P still waiting for its PV product all have to follow."""
+def test_attention_rowv_late_rescale_branch(ops):
+    """flash_attn2_kernel<3, rowV, plain, 8> (the d = 40 self-attention kernel the UNet runs) when the lazy softmax reference moves late:
+    a few keys far larger than the rest in late tiles, for some queries only — O^T and the running sum have to be rescaled then."""
     b, heads, l, d = 8, 8, 2304, 40
     q, k, v = r16((b, l, heads * d), 54), r16((b, l, heads * d), 55), r16((b, l, heads * d), 56)
     k[:, 2200] = q[:, 3] * 4.0
@@ -197,6 +197,24 @@ def test_attention_pipelined_rescale_branch(ops):
     assert rel_l2(y.float().cpu(), ref) < TOL
     for rows in ([3], [9], [700], [2303]):                      # the rows whose reference moved, on their own
         assert rel_l2(y[:, rows].float().cpu(), ref[:, rows]) < 2 * TOL
+
+
+def test_attention_rejects_row_strides_shorter_than_all_heads(ops):
+    """A row of q / k / v / o holds all heads side by side: a row stride below heads * d would make rows overlap."""
+    from lightdiffusion_amd._lib import LDError, lib, ERR_SHAPE
+    b, heads, l, d = 2, 8, 64, 40
+    c = heads * d
+    q, k, v = r16((b, l, c), 51).to(DEV), r16((b, l, c), 52).to(DEV), r16((b, l, c), 53).to(DEV)
+    o = torch.empty_like(q)
+    st = lib().ld_op_attention_rowv(q.data_ptr(), c, k.data_ptr(), c, v.data_ptr(), d, o.data_ptr(), c, b, heads, l, l, d, 0.158, 0, torch.cuda.current_stream().cuda_stream)
+    assert st == ERR_SHAPE
+    st = lib().ld_op_attention_rowv(q.data_ptr(), d, k.data_ptr(), c, v.data_ptr(), c, o.data_ptr(), c, b, heads, l, l, d, 0.158, 0, torch.cuda.current_stream().cuda_stream)
+    assert st == ERR_SHAPE
+    # fused [q | k | v] column blocks share one batch stride: only lq == lk is expressible
+    qkv = torch.cat([q, k, v], -1).contiguous()
+    st = lib().ld_op_attention_rowv(qkv.data_ptr(), 3 * c, qkv.data_ptr() + 2 * c, 3 * c, qkv.data_ptr() + 4 * c, 3 * c, o.data_ptr(), c, b, heads, l, l - 8, d, 0.158, 0,
+                                    torch.cuda.current_stream().cuda_stream)
+    assert st == ERR_SHAPE
 
 
 def test_causal_attention_row_major_v(ops):
@@ -470,3 +488,31 @@ def test_linear_ln_geglu(ops, M, C):
     ref = a * F.gelu(gt)
     assert rel_l2(y.float().cpu(), ref.cpu()) < 3e-3
     assert (y.float() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item() / 8)
+
+
+# ResBlock1's out_layers convolution + 1x1 skip_connection as ONE contraction (the executor's "skip fold": the skip sources are a second K
+# segment of the tap-major kernels, LD.py:5267, 5273-5287): every kernel of that family — 128 x 160 tiles, 64 x 160 tiles with a split over
+# K (the split may cut inside the skip segment), the 256 x 320 kernel — with one and two skip sources, against torch fp32
+@pytest.mark.parametrize("n,hw,c,sc1,sc2,cout,rv", [
+    (16, 32, 640, 1280, 640, 640, True),     # level 1 at UNet batch 16: gemm3<128,160,conv>, K = 5760 + 1920
+    (16, 8, 1280, 1280, 1280, 1280, True),   # level 3: split over K + reduce
+    (16, 64, 320, 640, 320, 320, False),     # level 0: 256 x 320 tiles (32-wide K steps)
+    (2, 32, 640, 320, 0, 640, True),         # input_blocks.4 at UNet batch 2: one skip source
+    (2, 16, 1280, 1280, 640, 1280, False),   # 64-row tiles, deep split
+    (4, 16, 1280, 640, 0, 1280, True)])      # input_blocks.7
+def test_conv3x3_with_skip_segment(ops, n, hw, c, sc1, sc2, cout, rv):
+    import math
+    x = r16((n, c, hw, hw), 301)
+    s1 = r16((n, sc1, hw, hw), 302, 2.0)
+    s2 = r16((n, sc2, hw, hw), 303) - 0.5 if sc2 else None
+    wt, b = r16((cout, c, 3, 3), 304, 1 / math.sqrt(9 * c)), r16((cout,), 305, 0.1)
+    wsk, bsk = r16((cout, sc1 + sc2, 1, 1), 306, 1 / math.sqrt(sc1 + sc2)), r16((cout,), 307, 0.1)
+    rowvec = r16((n, cout), 308) if rv else None
+    sx = s1.float() if s2 is None else torch.cat([s1.float(), s2.float()], 1)
+    ref = F.conv2d(x.float().to(DEV), wt.float().to(DEV), b.float().to(DEV), padding=1) + F.conv2d(sx.to(DEV), wsk.float().to(DEV), bsk.float().to(DEV))
+    if rv:
+        ref = ref + rowvec.float().to(DEV)[:, :, None, None]
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = ops.conv2d_skip(nh(x), ops.repack_conv_weight(wt.to(DEV)), b.to(DEV), nh(s1), None if s2 is None else nh(s2), wsk.reshape(cout, sc1 + sc2).contiguous().to(DEV),
+                        bsk.to(DEV), None if rowvec is None else rowvec.to(DEV))
+    assert rel_l2(y.permute(0, 3, 1, 2).float().cpu(), ref.cpu()) < TOL
