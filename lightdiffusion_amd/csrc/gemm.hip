@@ -643,9 +643,24 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
 //   producer kt:  wait until slab kt+1 has landed (counted vmcnt)             | BARRIER kt | issue slab kt+4 into the stage of kt
 // After BARRIER kt slab kt+1 is complete for everyone and nobody reads slab kt's stage any more.
 // =====================================================================================================================
-template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
-    constexpr int BK3 = 64, NST = 4;
+// "at most `ahead` slabs' worth of this wave's loads (LPT each) are still outstanding", ahead clamped to MAXA (counted vmcnt needs literals)
+template <int LPT, int MAXA>
+__device__ __forceinline__ void wait_slabs_ahead(int ahead) {
+    if constexpr (MAXA == 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (ahead >= MAXA) wait_vmcnt<MAXA * LPT>();
+        else wait_slabs_ahead<LPT, MAXA - 1>(ahead);
+    }
+}
+
+// NST: ring depth (a power of two; 4 in every shipped instantiation — 8 stages measured +-0, see launch_cfg).  WPS: waves per SIMD the
+// register allocation is bounded for — 4 lets TWO workgroups of the 64 x 64 tile share a CU (2 x 64 KB of LDS, 96 KB of slabs in flight)
+// where a skinny projection has more tiles than CUs.
+template <int BM, int BN, bool CONV, int NST = 4, int WPS = 2>
+__global__ __launch_bounds__(2 * NT, WPS) void gemm4_kernel(const GemmParams p) {
+    constexpr int BK3 = 64;
+    static_assert((NST & (NST - 1)) == 0 && NST >= 4, "ring depth");
     constexpr int WTM = BM / 2, WTN = BN / 2;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;
@@ -792,10 +807,7 @@ __global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
         auto wait_slab = [&](int kt, int issued_after) {
             int ahead = kt_end - 1 - kt;
             if (ahead > issued_after) ahead = issued_after;
-            if (ahead >= 3) wait_vmcnt<3 * LPT>();
-            else if (ahead == 2) wait_vmcnt<2 * LPT>();
-            else if (ahead == 1) wait_vmcnt<LPT>();
-            else wait_vmcnt<0>();
+            wait_slabs_ahead<LPT, NST - 1>(ahead);
         };
         if (CONV) conv_seek(kt_begin * BK3);
 #pragma unroll
@@ -805,6 +817,9 @@ __global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             wait_slab(kt + 1, NST - 2);                  // issued so far: up to kt + NST - 1
             __builtin_amdgcn_s_barrier();                // BARRIER kt
+#ifdef LD_AB_BUILD
+            if (p.dbg & 1) continue;                     // ablation (tools/gemm4_abl.py; wrong results, timing only): no DMA behind the prologue's NST slabs
+#endif
             issue(kt + NST);
         }
         wait_vmcnt<0>();
@@ -842,10 +857,16 @@ __global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
     read_frags(rd0, fa0, fb0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int st = 0;
+#ifdef LD_AB_BUILD
+    const bool no_rd = (p.dbg & 2) != 0, no_mm = (p.dbg & 4) != 0;   // ablations (tools/gemm4_abl.py): no fragment reads in the loop / no MFMAs
+    if (no_rd) read_frags(rd1, fa1, fb1);
+#else
+    constexpr bool no_rd = false, no_mm = false;
+#endif
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        read_frags(rd1, fa1, fb1);
+        if (!no_rd) read_frags(rd1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        mma(fa0, fb0);
+        if (!no_mm) mma(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                    // BARRIER kt
@@ -853,13 +874,16 @@ __global__ __launch_bounds__(2 * NT, 2) void gemm4_kernel(const GemmParams p) {
         rd0 += flip;
         rd1 += flip;
         st = (st + 1) & (NST - 1);
-        read_frags(rd0, fa0, fb0);
+        if (!no_rd) read_frags(rd0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        mma(fa1, fb1);
+        if (!no_mm) mma(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();                        // tail: the ring is quiet, producers leave
+#ifdef LD_AB_BUILD
+    if (p.dbg & 8) return;                               // ablation: no epilogue
+#endif
 
     if (splitk > 1) {
         float* part = p.partial + (long long)ks * p.M * p.N;
@@ -932,6 +956,53 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
     // (GEGLU keeps the predicated loop: with 40 accumulators of the next strips still live, the batched / interleaved form of the 128 x 160
     // kernel's epilogue spills here and measured 14 % slower per launch at 4096 x 10240 x 1280)
     if (EPI == 2) {   // GEGLU: the wave's 160 columns are one [80 value | 80 gate] block -> 80 outputs
+        if (rows_full) {
+            // Round 5: whole strips take the batched form — every global / LDS operand of the strip requested first, then the stage-by-stage
+            // GELUs of common.h (8 per chunk; with the one-transcendental GELU its live set is 40 registers: no spills next to the 80
+            // accumulators of the strips still waiting, which is what ruled this form out with round 4's GELU: -14 % per launch then).
+            // 160 chunk pairs over 64 lanes: two full rounds and one of 32 lanes (the others recompute chunk 0 and do not store).
+            half_t* Cb = p.C + (long long)z * p.sC + (long long)m_base * p.ldc + n_base / 2;
+            const bool hr = p.R != nullptr;
+            const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m_base * p.ldr + n_base / 2 : nullptr;
+            uint4 rba[3], rbg[3], rres[3], ca[3], cg[3];
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int q0 = lane + it * 64;
+                const int q = q0 < 160 ? q0 : 0;
+                const int row = q / 10, cc = q - row * 10;
+                rba[it] = ld16(p.bias_n + n_base + cc * 8);
+                rbg[it] = ld16(p.bias_n + n_base + cc * 8 + 80);
+                rres[it] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
+                ca[it] = ld16(Cs + row * V5_EPI_LD + cc * 8);
+                cg[it] = ld16(Cs + row * V5_EPI_LD + 80 + cc * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int q0 = lane + it * 64;
+                const int q = q0 < 160 ? q0 : 0;
+                const int row = q / 10, cc = q - row * 10;
+                float a[8], g[8], ba[8], bg[8], r[8];
+                unpack8(ca[it], a);
+                unpack8(cg[it], g);
+                unpack8(rba[it], ba);
+                unpack8(rbg[it], bg);
+                unpack8(rres[it], r);
+                f32x2 ap[4], gp[4], op[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ap[k] = (f32x2){a[2 * k] + ba[2 * k], a[2 * k + 1] + ba[2 * k + 1]};
+                    gp[k] = (f32x2){g[2 * k] + bg[2 * k], g[2 * k + 1] + bg[2 * k + 1]};
+                }
+                geglu8_staged_f32(ap, gp, op);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[2 * k] = op[k][0] + r[2 * k];
+                    a[2 * k + 1] = op[k][1] + r[2 * k + 1];
+                }
+                if (q0 < 160) st16(Cb + (long long)row * p.ldc + cc * 8, pack8(a));
+            }
+            return;
+        }
         uint4 rba[3], rbg[3], rres[3];
 #pragma unroll
         for (int it = 0; it < 3; ++it) {
@@ -2324,6 +2395,8 @@ const char* intern_name(const std::string& s) {   // stable storage for composed
     return pool.insert(s).first->c_str();
 }
 
+static bool two_wg_ok();   // (A/B hook, below)
+
 template <int BM, int BN>
 void launch_cfg(const GemmParams& p, hipStream_t s, bool deep = false) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -2331,6 +2404,19 @@ void launch_cfg(const GemmParams& p, hipStream_t s, bool deep = false) {
     dim3 grid(tiles * sk, 1, p.batch);
     // producer/consumer kernel: wins where a plain GEMM leaves at most one workgroup per CU (batch-1 step: +5.6 % whole step,
     // same box A/B); loses on convs and wherever two v3 workgroups share a CU.
+    if constexpr (BM == 64 && BN == 64) {
+        // skinny projections with more tiles than CUs: the producer / consumer kernel with two workgroups per CU (see gemm4_kernel, WPS).
+        // Measured per launch inside the batch-1 forward (tools/ab_launches.py 1 0 2048, profiles/r05_ab_gemm4_rings.txt): 2048 x 640 x 640
+        // (320 tiles, 10 slabs) 14.3 -> 11.7 us against the 2-stage kernel; 8192 x 320 x 320 (640 tiles, 5 slabs) 12.3 -> 14.4: short K stays.
+        // An 8-stage ring for <= 256 tiles measured +-0 (512 x 1280 x 1280: 13.6 vs 13.4 us): these launches are not short of bytes in
+        // flight — an ablated kernel that only runs its prologue and barriers takes 4.7 of 8.3 us (tools/gemm4_abl.py).
+        const long long blocks = (long long)tiles * sk * p.batch;
+        if (!p.conv && two_wg_ok() && blocks > V4_MAX_BLOCKS && blocks <= 512 && p.K >= 640) {
+            t_last_kernel = "gemm4_kernel<64,64,plain,2wg>";
+            hipLaunchKernelGGL((gemm4_kernel<64, 64, false, 4, 4>), grid, dim3(2 * NT), 0, s, p);
+            return;
+        }
+    }
     if (!p.conv && (long long)tiles * sk * p.batch <= V4_MAX_BLOCKS) {
         static const std::string name = "gemm4_kernel<" + std::to_string(BM) + "," + std::to_string(BN) + ",plain>";
         t_last_kernel = name.c_str();
@@ -2372,6 +2458,16 @@ static int g_v5_dbg = 0;
 extern "C" void ld_debug_gemm_v5_dbg(int bits) { g_v5_dbg = bits; }   // 1: no DMA issue in the loop, 2: no fragment reads, 4: 4 of 40 MFMAs
 #endif
 
+namespace {
+bool two_wg_ok() {
+#ifdef LD_AB_BUILD
+    return (g_no_v5 & 2048) == 0;    // A/B: bit 2048 keeps round 4's 2-stage kernel for the 64 x 64 tiles beyond 256 workgroups
+#else
+    return true;
+#endif
+}
+}  // namespace
+
 // the split-K second pass of a launch: the plain reduce, or the one that also emits GroupNorm partials (GemmParams::gn_part)
 static void launch_splitk_reduce(const GemmParams& p, int bn, hipStream_t stream) {
     // (N >= 256: below that gn_stats_kernel uses fewer, wider channel slabs — norm.hip gn_slabs — and this kernel's four-slab order would
@@ -2403,6 +2499,15 @@ static bool v7_geglu_enabled() {
     return (g_no_v5 & 16) == 0;      // A/B: bit 16 sends GEGLU back to the 128 x 160 kernel
 #else
     return true;
+#endif
+}
+
+// smallest K of a GEGLU the 256 x 320 kernel takes (round 4: 1280 — its strip epilogue ran the GELUs unbatched)
+static int v5_geglu_min_k() {
+#ifdef LD_AB_BUILD
+    return (g_no_v5 & 1024) ? 640 : 1280;      // A/B: bit 1024 also sends the K = 640 GEGLU (level 1) there
+#else
+    return 1280;
 #endif
 }
 
@@ -2639,7 +2744,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         // a split over K (4096 x 1280 x 11520: the 128 x 160 kernel's own split is 3 % ahead)
         const bool conv3 = p.conv && p.ksize == 3;
         const bool shape_ok = !p.ln_swapped && p.bm == 0 && (p.bn == 0 || p.bn == 160) && p.N % V5_BN == 0 && p.K % V5_BK == 0 &&
-                              p.K >= (p.act == 2 ? 1280 : conv3 ? 640 : 2560) && (p.n_valid == p.N || p.n_valid <= 0 || p.n_valid > p.N) &&
+                              p.K >= (p.act == 2 ? v5_geglu_min_k() : conv3 ? 640 : 2560) && (p.n_valid == p.N || p.n_valid <= 0 || p.n_valid > p.N) &&
                               p.splitk == 0 && p.M >= 1024;
 #ifdef LD_AB_BUILD
         if (shape_ok && !(g_no_v5 & 1)) {

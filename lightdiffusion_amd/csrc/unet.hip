@@ -371,22 +371,13 @@ struct Run {
         };
         half_t* g1 = ar.halfs(M * r.cin);
         half_t* h1 = ar.halfs(M * r.cout);
-        // the GroupNorm statistics of h1 (out_layers' norm) come from conv1's split-K second pass where it has one (gemm.h gn_part)
-        float* gnp = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(na(), H * W)));
-        int gnp_done = 0;
-        {
-            GemmParams c1 = conv_params(x1, C1, x2, C2, r.c1_w, r.c1_b, emb_all + r.emb_off, u->emb_total, nullptr, h1);
-            want_stats(c1, gnp, H * W, &gnp_done);
-            ex.gn_silu_conv(c1, n, H * W, P(r.gn1_g), P(r.gn1_b), 1e-5f, g1, in_stats, in_P);
-        }
-        half_t* g2 = g1;   // g1 is dead once conv1 has consumed it (stream order); reuse when it is large enough
-        if (r.cout > r.cin) g2 = ar.halfs(M * r.cout);
+        // The 1x1 skip_connection (LD.py:5267): folded into out_layers' convolution as a second K segment where that convolution runs on a
+        // tap-major kernel (same FLOPs at the 3x3 kernels' rate, one launch and one [M][cout] round trip less); a launch of its own in front
+        // of the halo-tile and row-resident kernels.  (On a second stream beside in_layers in a batch-1 step it measured 2.9 % SLOWER than in
+        // order: tools/experiments/fork_join_skip_conv_r05.patch.txt.)
         const half_t* skip = x1;
         bool fold_skip = false;
         if (r.sk_w >= 0) {
-            // the 1x1 skip_connection: a second K segment of out_layers' convolution (same FLOPs at the 3x3 kernels' rate, one launch and one
-            // [M][cout] round trip less) where that convolution runs on a tap-major kernel; a separate launch in front of the halo-tile and
-            // row-resident kernels
             GemmParams probe = conv_params(h1, r.cout, nullptr, 0, r.c2_w, r.c2_b, nullptr, 0, nullptr, out);
             fold_skip = u->ln_fold && u->fold_base != nullptr && ex.conv_takes_skip_segment(probe);
 #ifdef LD_AB_BUILD
@@ -398,6 +389,16 @@ struct Run {
                 skip = sk;
             }
         }
+        // the GroupNorm statistics of h1 (out_layers' norm) come from conv1's split-K second pass where it has one (gemm.h gn_part)
+        float* gnp = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(na(), H * W)));
+        int gnp_done = 0;
+        {
+            GemmParams c1 = conv_params(x1, C1, x2, C2, r.c1_w, r.c1_b, emb_all + r.emb_off, u->emb_total, nullptr, h1);
+            want_stats(c1, gnp, H * W, &gnp_done);
+            ex.gn_silu_conv(c1, n, H * W, P(r.gn1_g), P(r.gn1_b), 1e-5f, g1, in_stats, in_P);
+        }
+        half_t* g2 = g1;   // g1 is dead once conv1 has consumed it (stream order); reuse when it is large enough
+        if (r.cout > r.cin) g2 = ar.halfs(M * r.cout);
         {
             GemmParams c2 = conv_params(h1, r.cout, nullptr, 0, r.c2_w, r.c2_b, nullptr, 0, skip, out);
             if (fold_skip) {

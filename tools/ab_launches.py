@@ -18,8 +18,9 @@ u.set_context(torch.randn(2 * B, 77, 768))
 x = torch.randn(2 * B, 4, hw, hw, device='cuda'); s = torch.full((2 * B,), 3.0, device='cuda')
 runs = {}
 for f in sets:
-    L.ld_debug_gemm_no_v5(f if f < 1000 else 0)
-    L.ld_debug_gemm_override(f - 1000 if f >= 1000 else 0, 0)     # flag sets >= 1000: force tile height (f - 1000) on the 128 x 160 family
+    tile = f in (1064, 1128)                                      # 1064 / 1128: force tile height 64 / 128 on the 128 x 160 family; anything else: ld_debug_gemm_no_v5 bits
+    L.ld_debug_gemm_no_v5(0 if tile else f)
+    L.ld_debug_gemm_override(f - 1000 if tile else 0, 0)
     for _ in range(2): u.forward(x, s)
     torch.cuda.synchronize()
     best = None
