@@ -264,7 +264,8 @@ def main():
         # set-up, before the W warm-up steps (like loading the weights): the first call of a shape plans the workspace and captures
         # the step's hipGraph; one schedule pass brings the clocks out of idle
         if not args.no_prime:
-            passes(run_len)
+            for _ in range(int(os.environ.get("LD_BENCH_PRIME_PASSES", "1"))):      # (experiments: how long the clocks take to settle)
+                passes(run_len)
             torch.cuda.synchronize()
         passes(Wm)
         barrier()

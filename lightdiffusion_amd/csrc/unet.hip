@@ -902,6 +902,9 @@ int ld_unet_reserve(ld_unet* u, int max_n, int max_h, int max_w, int max_tok) {
         u->ctx_vt[i] = reinterpret_cast<half_t*>(p);
         p += b;
     }
+    if (getenv("LD_PROFILE_DUMP") != nullptr)   // (where the allocations landed: tools/alloc_probe.py)
+        fprintf(stderr, "[ld_reserve] workspace %p (%zu MiB)  weights %p  folds %p  conv8 weights %p\n", (void*)u->ws_base, u->ws_bytes >> 20, (void*)u->pt.base,
+                (void*)u->fold_base, (void*)u->w8_base);
     u->max_n = max_n;
     u->max_h = max_h;
     u->max_w = max_w;
