@@ -57,8 +57,44 @@ __device__ __forceinline__ void epilogue_store8(const GemmParams& p, int z, int 
 // fused epilogue (bias, time-embedding row vector, residual) are loaded FIRST for every chunk, then consumed: the
 // loads overlap each other instead of paying one full memory latency per chunk (the accumulators are dead here, so
 // the registers are free).
+// Round 5 (tools/gemm3_abl.py, profiles/r05_gemm3_ablations.txt: at 16384 x 640 x 640 the tile epilogue took 8.7 of 23.5 us, 4.6 of them with
+// neither residual loads nor stores): the epilogue no longer starts a memory round trip of its own.  `bias_s` = this tile's BN bias halfs,
+// staged in LDS by the kernel's prologue (zeros when there is no bias); `pre` = the residual chunks of the first group of the plain interior
+// path, requested by the caller BEFORE the tile is staged in LDS (epi_prefetch_residual); the second group's are requested before the first
+// group is consumed.
 template <int BM, int BN>
-__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t* Cs, int z, int m0, int n0, int tid, float* lds_scratch = nullptr) {
+struct EpiPre {
+    static constexpr int CPR = BN / 8, EIT = (BM * CPR + NT - 1) / NT, GRP = EIT > 5 ? (EIT + 1) / 2 : EIT;
+    uint4 r[GRP];
+    bool fast;        // the plain interior path runs (workgroup-uniform)
+    bool bias_done;   // the bias is already in the staged tile (accumulator start value / LayerNorm-fold finish): the epilogue adds none
+};
+template <int BM, int BN>
+__device__ __forceinline__ EpiPre<BM, BN> epi_prefetch_residual(const GemmParams& p, int z, int m0, int n0, int tid, bool bias_done) {
+    EpiPre<BM, BN> e;
+    e.bias_done = bias_done;
+    constexpr int CPR = EpiPre<BM, BN>::CPR, GRP = EpiPre<BM, BN>::GRP;
+    e.fast = (BM * CPR) % NT == 0 && m0 + BM <= p.M && n0 + BN <= p.N && p.act == 0 && p.bias_m == nullptr && bias_done;
+#pragma unroll
+    for (int k = 0; k < GRP; ++k) e.r[k] = zero16();
+#ifdef LD_AB_BUILD
+    if (p.dbg & 32) return e;
+#endif
+    if (e.fast && p.R != nullptr) {
+        const half_t* Rb = p.R + (long long)z * p.sR + (long long)m0 * p.ldr + n0;
+#pragma unroll
+        for (int k = 0; k < GRP; ++k) {
+            const int q = tid + k * NT;
+            const int row = q / CPR, cc = q - row * CPR;
+            e.r[k] = ld16(Rb + (long long)row * p.ldr + cc * 8);
+        }
+    }
+    return e;
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t* Cs, int z, int m0, int n0, int tid, float* lds_scratch, const half_t* bias_s,
+                                              const EpiPre<BM, BN>& pre) {
     constexpr int CLD = BN + 8;
     if (p.act == 2) {
         constexpr int CPR = BN / 16;
@@ -72,8 +108,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
             for (int it = 0; it < EIT; ++it) {
                 const int q = tid + it * NT;
                 const int row = q / CPR, cc = q - row * CPR;
-                rba[it] = ld16(p.bias_n + n0 + cc * 8);
-                rbg[it] = ld16(p.bias_n + n0 + cc * 8 + BN / 2);
+                rba[it] = ld16(bias_s + cc * 8);
+                rbg[it] = ld16(bias_s + cc * 8 + BN / 2);
                 rres[it] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
                 ca[it] = ld16(Cs + row * CLD + cc * 8);
                 cg[it] = ld16(Cs + row * CLD + BN / 2 + cc * 8);
@@ -136,26 +172,43 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
         constexpr int CPR = BN / 8;
         constexpr int EIT = (BM * CPR + NT - 1) / NT;
         constexpr int GRP = EIT > 5 ? (EIT + 1) / 2 : EIT;   // two passes for the big tiles: bounds the live registers
-        const bool hb = p.bias_n != nullptr, hv = p.rowvec != nullptr, hr = p.R != nullptr;
-        // Interior tiles without an activation: a branch-free path — no per-chunk predicate, so the LDS and
-        // global reads of a group go out as one batch and are waited for once (the predicated loop below reads, waits and converts
-        // chunk by chunk: measured 12..22 % of the whole launch on the K = 640 / 1280 projections); fp16 pairs converted packed.
-        if ((BM * CPR) % NT == 0 && m0 + BM <= p.M && n0 + BN <= p.N && p.act == 0) {
+#ifdef LD_AB_BUILD
+        const bool hb = p.bias_n != nullptr && !pre.bias_done, hv = p.rowvec != nullptr, hr = p.R != nullptr && !(p.dbg & 32);   // ablations (tools/gemm3_abl.py): 32 no residual loads, 64 no output stores
+        const bool no_st = (p.dbg & 64) != 0;
+#else
+        const bool hb = p.bias_n != nullptr && !pre.bias_done, hv = p.rowvec != nullptr, hr = p.R != nullptr;
+        constexpr bool no_st = false;
+#endif
+        // Interior tiles without an activation: a branch-free path in PACKED fp16 (round 5; tools/gemm3_abl.py: with neither residual loads
+        // nor stores the fp32 form of this path still took 4.6 of 23.5 us at 16384 x 640 x 640 — ~70 vector instructions per 16-byte chunk,
+        // two workgroups per CU).  The bias is in the staged tile already (accumulator start value, or the LayerNorm-fold finish), so a chunk
+        // is: tile chunk (+ time-embedding row) (+ residual) by v_pk_add_f16 — the sum of two fp16 values is exact in fp32, so one packed add
+        // rounds exactly like the fp32 form did — and the LayerNorm-fold row statistics by v_dot2_f32_f16 on the packed result.
+        if (pre.fast) {
+            static_assert(GRP == EpiPre<BM, BN>::GRP, "group size");
             half_t* Cb = p.C + (long long)z * p.sC + (long long)m0 * p.ldc + n0;
             const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m0 * p.ldr + n0 : nullptr;
+            uint4 rnext[GRP];                                   // the residual chunks of the group after the one being consumed
+#pragma unroll
+            for (int k = 0; k < GRP; ++k) rnext[k] = pre.r[k];
 #pragma unroll
             for (int g0 = 0; g0 < EIT; g0 += GRP) {
-                uint4 rb[GRP], rv[GRP], rres[GRP], cv[GRP];
-                half_t rm[GRP];
+                uint4 rv[GRP], rres[GRP], cv[GRP];
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) rres[k] = rnext[k];
+#pragma unroll
+                for (int k = 0; k < GRP; ++k) {                 // next group's residual: in flight while this group is consumed
+                    if (g0 + GRP + k >= EIT) continue;
+                    const int q = tid + (g0 + GRP + k) * NT;
+                    const int row = q / CPR, cc = q - row * CPR;
+                    rnext[k] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
+                }
 #pragma unroll
                 for (int k = 0; k < GRP; ++k) {
                     if (g0 + k >= EIT) continue;
                     const int q = tid + (g0 + k) * NT;
                     const int row = q / CPR, cc = q - row * CPR;
-                    rm[k] = p.bias_m != nullptr ? p.bias_m[m0 + row] : (half_t)0.f;
-                    rb[k] = hb ? ld16(p.bias_n + n0 + cc * 8) : zero16();
                     rv[k] = hv ? ld16(p.rowvec + (long long)((m0 + row) / p.rows_per_vec) * p.ldrv + n0 + cc * 8) : zero16();
-                    rres[k] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
                     cv[k] = ld16(Cs + row * CLD + cc * 8);
                 }
 #pragma unroll
@@ -163,25 +216,18 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
                     if (g0 + k >= EIT) continue;
                     const int q = tid + (g0 + k) * NT;
                     const int row = q / CPR, cc = q - row * CPR;
-                    float v[8], b[8], e[8], r[8];
-                    unpack8(cv[k], v);
-                    unpack8(rb[k], b);
-                    unpack8(rv[k], e);
-                    unpack8(rres[k], r);
-                    const float bm = (float)rm[k];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = v[j] + b[j] + bm + e[j] + r[j];       // (the same association as the general loop)
-                    const uint4 packed = pack8(v);
-                    st16(Cb + (long long)row * p.ldc + cc * 8, packed);
+                    uint4 packed = cv[k];
+                    if (hv) packed = add8h(packed, rv[k]);
+                    if (hr) packed = add8h(packed, rres[k]);
+                    if (!no_st) st16(Cb + (long long)row * p.ldc + cc * 8, packed);
                     if (lds_scratch != nullptr) {   // LN-fold producer: row statistics of what was actually stored (the fp16 values)
-                        float f[8];
-                        unpack8(packed, f);
-                        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            s1 += f[j];
-                            s2 += f[j] * f[j];
-                        }
+                        const half2v one2 = {(half_t)1.f, (half_t)1.f};
+                        const half2v h0 = __builtin_bit_cast(half2v, packed.x), h1 = __builtin_bit_cast(half2v, packed.y);
+                        const half2v h2 = __builtin_bit_cast(half2v, packed.z), h3 = __builtin_bit_cast(half2v, packed.w);
+                        float s1 = __builtin_amdgcn_fdot2(h1, one2, __builtin_amdgcn_fdot2(h0, one2, 0.f, false), false);
+                        float s2 = __builtin_amdgcn_fdot2(h1, h1, __builtin_amdgcn_fdot2(h0, h0, 0.f, false), false);
+                        s1 = __builtin_amdgcn_fdot2(h3, one2, __builtin_amdgcn_fdot2(h2, one2, s1, false), false);
+                        s2 = __builtin_amdgcn_fdot2(h3, h3, __builtin_amdgcn_fdot2(h2, h2, s2, false), false);
                         *reinterpret_cast<float2*>(lds_scratch + q * 2) = make_float2(s1, s2);
                     }
                 }
@@ -309,19 +355,22 @@ __device__ __forceinline__ void ln_prepare(const GemmParams& p, float* ln_mu, fl
 
 template <int TM, int TN>
 __device__ __forceinline__ void ln_apply(const GemmParams& p, f32x4 (&acc)[TM][TN], const float* ln_mu, const float* ln_rs, int m0, int n0, int wm0,
-                                         int wn0, int fr, int fq) {
+                                         int wn0, int fr, int fq, const float* wsum_s, const half_t* bias_s, bool add_bias) {
     if (!p.ln_swapped) {
-        f32x4 ws[TN];
+        f32x4 ws[TN], bj[TN];  // this tile's row sums and (add_bias: act == 0, the epilogue then adds none) its bias / alpha, staged in LDS by the kernel's prologue
+        const float inv_alpha = 1.0f / p.alpha;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn0 + j * 16 + fq * 4;
-            ws[j] = n < p.N ? *reinterpret_cast<const f32x4*>(p.ln_wsum + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            ws[j] = *reinterpret_cast<const f32x4*>(wsum_s + wn0 + j * 16 + fq * 4);
+            const half4 bh = *reinterpret_cast<const half4*>(bias_s + wn0 + j * 16 + fq * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bj[j][r] = add_bias ? (float)bh[r] * inv_alpha : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const float mu = ln_mu[wm0 + i * 16 + fr], rs = ln_rs[wm0 + i * 16 + fr];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = (acc[i][j] - mu * ws[j]) * rs;
+            for (int j = 0; j < TN; ++j) acc[i][j] = (acc[i][j] - mu * ws[j]) * rs + bj[j];
         }
     } else {
 #pragma unroll
@@ -340,6 +389,30 @@ __device__ __forceinline__ void ln_apply(const GemmParams& p, f32x4 (&acc)[TM][T
 
 __device__ uint4 g_zero_row[4096];  // 64 KB of zeros: conv taps outside the image read it, stepped through like real data (one
                                     // tap's channel run at a time, so it only has to cover max(C1, C2) <= 32768 halfs)
+
+// Prologue staging of a tile's per-column epilogue operands into LDS: bias_s[BN] halfs (zeros without a bias) and, for a LayerNorm-fold
+// consumer, wsum_s[BN] floats (zeros beyond N).  epi_stage_load issues the two loads as untracked asm (always a load, from a page of zeros
+// where there is nothing to fetch) BEFORE the first LDS-DMA of the wave, so they are its oldest vector-memory operations;
+// EPI_STAGE_WAIT(KEEP, ..) waits with a COUNTED vmcnt that leaves the KEEP LDS-DMA instructions issued since in flight (KEEP = 0 where the
+// wave issues none, or fewer than the full prologue) and names the destination registers as operands of that wait (DESIGN "hipcc traps" (c));
+// epi_stage_store writes them to LDS; the slab loop's barriers publish them long before the epilogue reads them.
+// (the loaded values live in two f32x4 locals of the KERNEL — b: 8 bias halfs as a bit pattern, w: 4 row sums — so that the counted wait
+// can name them as read-write operands: nothing that copies or spills them can be scheduled between a load and the wait)
+template <int BN>
+__device__ __forceinline__ void epi_stage_load(const GemmParams& p, int n0, int t, f32x4& b, f32x4& w) {   // t: thread index inside the loading role (>= BN / 4 threads)
+    const char* zp = reinterpret_cast<const char*>(g_zero_row);
+    const char* bp = (t < BN / 8 && p.bias_n != nullptr && n0 + t * 8 < p.N) ? reinterpret_cast<const char*>(p.bias_n + n0 + t * 8) : zp;
+    const char* wp = (t < BN / 4 && p.ln_wsum != nullptr && !p.ln_swapped && n0 + t * 4 < p.N) ? reinterpret_cast<const char*>(p.ln_wsum + n0 + t * 4) : zp;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(b) : "v"(bp) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(w) : "v"(wp) : "memory");
+}
+#define EPI_STAGE_WAIT(KEEP, b, w) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b), "+v"(w) : "n"(KEEP) : "memory")
+template <int BN>
+__device__ __forceinline__ void epi_stage_store(const f32x4& b, const f32x4& w, half_t* bias_s, float* wsum_s, int t) {   // (behind EPI_STAGE_WAIT)
+    if (t < BN / 8) *reinterpret_cast<f32x4*>(bias_s + t * 8) = b;
+    if (t < BN / 4) *reinterpret_cast<f32x4*>(wsum_s + t * 4) = w;
+}
+
 
 // =====================================================================================================================
 // v3: 64-wide K slabs, a TWO-stage LDS-DMA ring (2 x (BM+BN) x 128 B <= 73.7 KB) and two workgroups per CU.
@@ -380,6 +453,8 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
     static_assert((BM * CLD * 2 + 15) / 16 * 16 + BM * (BN / 8) * 8 <= NST * STAGE * 2, "LN-fold row statistics must fit behind the epilogue tile");
     __shared__ __attribute__((aligned(16))) half_t smem[NST * STAGE];
     __shared__ __attribute__((aligned(16))) float ln_mu[BM > BN ? BM : BN], ln_rs[BM > BN ? BM : BN];
+    __shared__ __attribute__((aligned(16))) half_t bias_s[BN];
+    __shared__ __attribute__((aligned(16))) float wsum_s[BN];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -562,39 +637,70 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
             else wait_vmcnt<0>();
         }
     };
+    f32x4 est_b, est_w;
+    epi_stage_load<BN>(p, n0, tid, est_b, est_w);   // (before the first LDS-DMA: see epi_stage_load)
 #pragma unroll
     for (int t = 0; t < PF; ++t) issue(kt_begin + t, t);
     // LN fold: finish (mu, rstd) of this tile's LN rows while the first slabs are in flight (the slab loop's barriers publish it)
     if (p.ln_stat != nullptr) ln_prepare<BM, BN>(p, ln_mu, ln_rs, z, m0, n0, tid);
+    if (kt_end - kt_begin >= PF) EPI_STAGE_WAIT(PF * (A_IT + B_IT), est_b, est_w);   // (every issue() above went out: A_IT + B_IT instructions each)
+    else EPI_STAGE_WAIT(0, est_b, est_w);
+    epi_stage_store<BN>(est_b, est_w, bias_s, wsum_s, tid);
     wait_slab(kt_begin);
     __builtin_amdgcn_s_barrier();
     issue(kt_begin + PF, PF);
+    // the bias (zeros without one) is the accumulators' START value where the epilogue is a plain one (no activation, no split over K, no
+    // LayerNorm-fold finish, which adds it itself): the staged tile then holds acc * alpha + bias rounded ONCE, and the epilogue adds none
+    const bool bias_acc = splitk == 1 && p.ln_stat == nullptr && p.act == 0;
+    const bool bias_done = bias_acc || (splitk == 1 && p.ln_stat != nullptr && !p.ln_swapped && p.act == 0);
+    if (bias_acc) {
+        const float inv_alpha = 1.0f / p.alpha;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const half4 bh = *reinterpret_cast<const half4*>(bias_s + wn0 + j * 16 + fq * 4);
+            f32x4 bf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bf[r] = (float)bh[r] * inv_alpha;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = bf;
+        }
+    }
     read_frags(rd0, fa0, fb0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int st = 0;
+#ifdef LD_AB_BUILD
+    // ablations (tools/gemm3_abl.py; wrong results, timing only): 1 no DMA behind the prologue, 2 no fragment reads in the loop, 4 no MFMAs, 8 no epilogue
+    const bool no_dma = (p.dbg & 1) != 0, no_rd = (p.dbg & 2) != 0, no_mm = (p.dbg & 4) != 0;
+    if (no_rd) read_frags(rd1, fa1, fb1);
+#else
+    constexpr bool no_dma = false, no_rd = false, no_mm = false;
+#endif
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         // k-step 0 of slab kt sits in set 0; fetch k-step 1 under its MFMAs, then (slab kt+1 landed for everyone, stage st
         // free) refill st with slab kt+NST and fetch k-step 0 of slab kt+1 under the k-step-1 MFMAs
-        read_frags(rd1, fa1, fb1);
+        if (!no_rd) read_frags(rd1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
-        mma(fa0, fb0);
+        if (!no_mm) mma(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wait_slab(kt + 1);
         __builtin_amdgcn_s_barrier();
-        issue(kt + NST, st);
+        if (!no_dma) issue(kt + NST, st);
         const int flip = (st == NST - 1) ? -(NST - 1) * STAGE : STAGE;   // halfs to the next stage of the ring
         rd0 += flip;
         rd1 += flip;
         st = (st + 1) & (NST - 1);
-        read_frags(rd0, fa0, fb0);
+        if (!no_rd) read_frags(rd0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        mma(fa1, fb1);
+        if (!no_mm) mma(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+#ifdef LD_AB_BUILD
+    if (p.dbg & 8) return;
+#endif
 
     if (splitk > 1) {
         float* part = p.partial + (long long)ks * p.M * p.N;
@@ -614,7 +720,8 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
         return;
     }
     half_t* Cs = smem;
-    if (p.ln_stat != nullptr) ln_apply<TM, TN>(p, acc, ln_mu, ln_rs, m0, n0, wm0, wn0, fr, fq);
+    const EpiPre<BM, BN> pre = epi_prefetch_residual<BM, BN>(p, z, m0, n0, tid, bias_done);   // in flight while the tile is staged
+    if (p.ln_stat != nullptr) ln_apply<TM, TN>(p, acc, ln_mu, ln_rs, m0, n0, wm0, wn0, fr, fq, wsum_s, bias_s, bias_done);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int ml = wm0 + i * 16 + fr;
@@ -629,7 +736,7 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
     }
     __syncthreads();
     float* scratch = p.stat_out != nullptr ? reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + (BM * CLD * 2 + 15) / 16 * 16) : nullptr;
-    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid, scratch);
+    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid, scratch, bias_s, pre);
 }
 
 // =====================================================================================================================
@@ -671,6 +778,8 @@ __global__ __launch_bounds__(2 * NT, WPS) void gemm4_kernel(const GemmParams p) 
     static_assert(BM * CLD <= NST * STAGE, "epilogue tile must fit in the ring");
     __shared__ __attribute__((aligned(16))) half_t smem[NST * STAGE];
     __shared__ __attribute__((aligned(16))) float ln_mu[BM > BN ? BM : BN], ln_rs[BM > BN ? BM : BN];
+    __shared__ __attribute__((aligned(16))) half_t bias_s[BN];
+    __shared__ __attribute__((aligned(16))) float wsum_s[BN];
 
     const int lane = threadIdx.x & 63;
     const int wid8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -828,6 +937,12 @@ __global__ __launch_bounds__(2 * NT, WPS) void gemm4_kernel(const GemmParams p) 
     }
 
     // ---------------------------------------------------------------------- consumers
+    {   // this tile's bias / LayerNorm-fold row sums into LDS (EpiStage; the consumers issue no LDS-DMA)
+        f32x4 est_b, est_w;
+        epi_stage_load<BN>(p, n0, tid, est_b, est_w);
+        EPI_STAGE_WAIT(0, est_b, est_w);
+        epi_stage_store<BN>(est_b, est_w, bias_s, wsum_s, tid);
+    }
     if (p.ln_stat != nullptr) ln_prepare<BM, BN>(p, ln_mu, ln_rs, z, m0, n0, tid);   // (the slab loop's barriers publish it)
     const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
     const int fr = lane & 15, fq = lane >> 4;
@@ -854,6 +969,21 @@ __global__ __launch_bounds__(2 * NT, WPS) void gemm4_kernel(const GemmParams p) 
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     };
     __builtin_amdgcn_s_barrier();                        // P
+    // (bias as the accumulators' start value: see gemm3_kernel)
+    const bool bias_acc = splitk == 1 && p.ln_stat == nullptr && p.act == 0;
+    const bool bias_done = bias_acc || (splitk == 1 && p.ln_stat != nullptr && !p.ln_swapped && p.act == 0);
+    if (bias_acc) {
+        const float inv_alpha = 1.0f / p.alpha;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const half4 bh = *reinterpret_cast<const half4*>(bias_s + wn0 + j * 16 + fq * 4);
+            f32x4 bf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bf[r] = (float)bh[r] * inv_alpha;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = bf;
+        }
+    }
     read_frags(rd0, fa0, fb0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int st = 0;
@@ -903,7 +1033,8 @@ __global__ __launch_bounds__(2 * NT, WPS) void gemm4_kernel(const GemmParams p) 
         return;
     }
     half_t* Cs = smem;
-    if (p.ln_stat != nullptr) ln_apply<TM, TN>(p, acc, ln_mu, ln_rs, m0, n0, wm0, wn0, fr, fq);
+    const EpiPre<BM, BN> pre = epi_prefetch_residual<BM, BN>(p, z, m0, n0, tid, bias_done);   // in flight while the tile is staged
+    if (p.ln_stat != nullptr) ln_apply<TM, TN>(p, acc, ln_mu, ln_rs, m0, n0, wm0, wn0, fr, fq, wsum_s, bias_s, bias_done);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int ml = wm0 + i * 16 + fr;
@@ -918,7 +1049,7 @@ __global__ __launch_bounds__(2 * NT, WPS) void gemm4_kernel(const GemmParams p) 
     }
     __syncthreads();                                     // consumers only: the producers have exited
     float* scratch = p.stat_out != nullptr ? reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + (BM * CLD * 2 + 15) / 16 * 16) : nullptr;
-    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid, scratch);
+    epilogue_tile<BM, BN>(p, Cs, z, m0, n0, tid, scratch, bias_s, pre);
 }
 
 // =====================================================================================================================
