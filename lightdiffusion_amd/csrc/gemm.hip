@@ -1082,7 +1082,7 @@ constexpr int V5_SWZ = 0x78;                         // g[x] = (0x78 >> 2x) & 3 
 // into one kernel hipcc spilled 160 registers there and the LayerNorm-folded GEGLU of level 2 ran at 234 us instead of 140):
 //   0 plain (bias / row vector / activation / residual), 1 plain + LayerNorm-fold statistics out, 2 GEGLU
 template <int EPI>
-__device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* Cs, int z, int m_base, int n_base, int lane, int part) {
+__device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* Cs, int z, int m_base, int n_base, int lane, int part, bool bias_done) {
     const bool rows_full = m_base + 16 <= p.M;                          // (wave-uniform) every row of the strip exists: the branch-free paths
     // (GEGLU keeps the predicated loop: with 40 accumulators of the next strips still live, the batched / interleaved form of the 128 x 160
     // kernel's epilogue spills here and measured 14 % slower per launch at 4096 x 10240 x 1280)
@@ -1164,48 +1164,39 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
         }
         return;
     }
-    const bool hb = p.bias_n != nullptr, hv = p.rowvec != nullptr, hr = p.R != nullptr;
-    if (rows_full && p.bias_m == nullptr && p.act == 0) {   // branch-free: LDS reads and global operands go out in batches (3 + 2 chunks: registers)
+    const bool hb = p.bias_n != nullptr && !bias_done, hv = p.rowvec != nullptr, hr = p.R != nullptr;
+    if (rows_full && p.bias_m == nullptr && p.act == 0 && bias_done) {
+        // branch-free, all five chunks of a lane requested as one batch, and in PACKED fp16 (round 5, as the 128 x 160 kernel's tile epilogue:
+        // the bias is in the staged strip already — v5_finish adds it in fp32 before the one rounding — so a chunk is strip (+ time-embedding
+        // row) (+ residual) by v_pk_add_f16, exact sums rounded once, and the LayerNorm-fold row statistics come from v_dot2_f32_f16)
         half_t* Cb = p.C + (long long)z * p.sC + (long long)m_base * p.ldc + n_base;
         const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m_base * p.ldr + n_base : nullptr;
         float s1[5], s2[5];
+        uint4 rv[5], rres[5], cv[5];
 #pragma unroll
-        for (int g0 = 0; g0 < 5; g0 += 3) {
-            uint4 rb[3], rv[3], rres[3], cv[3];
+        for (int k = 0; k < 5; ++k) {
+            const int q = lane + k * 64;
+            const int row = q / 20, cc = q - row * 20;
+            rv[k] = hv ? ld16(p.rowvec + (long long)((m_base + row) / p.rows_per_vec) * p.ldrv + n_base + cc * 8) : zero16();
+            rres[k] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
+            cv[k] = ld16(Cs + row * V5_EPI_LD + cc * 8);
+        }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (g0 + k >= 5) continue;
-                const int q = lane + (g0 + k) * 64;
-                const int row = q / 20, cc = q - row * 20;
-                rb[k] = hb ? ld16(p.bias_n + n_base + cc * 8) : zero16();
-                rv[k] = hv ? ld16(p.rowvec + (long long)((m_base + row) / p.rows_per_vec) * p.ldrv + n_base + cc * 8) : zero16();
-                rres[k] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
-                cv[k] = ld16(Cs + row * V5_EPI_LD + cc * 8);
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (g0 + k >= 5) continue;
-                const int q = lane + (g0 + k) * 64;
-                const int row = q / 20, cc = q - row * 20;
-                float v[8], b[8], e[8], r[8];
-                unpack8(cv[k], v);
-                unpack8(rb[k], b);
-                unpack8(rv[k], e);
-                unpack8(rres[k], r);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = v[j] + b[j] + 0.f + e[j] + r[j];      // (the same association as the general loop)
-                const uint4 packed = pack8(v);
-                st16(Cb + (long long)row * p.ldc + cc * 8, packed);
-                if (EPI == 1 && p.stat_out != nullptr) {   // LN-fold producer: row statistics of the stored fp16 values
-                    float f[8];
-                    unpack8(packed, f);
-                    s1[g0 + k] = s2[g0 + k] = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        s1[g0 + k] += f[j];
-                        s2[g0 + k] += f[j] * f[j];
-                    }
-                }
+        for (int k = 0; k < 5; ++k) {
+            const int q = lane + k * 64;
+            const int row = q / 20, cc = q - row * 20;
+            uint4 packed = cv[k];
+            if (hv) packed = add8h(packed, rv[k]);
+            if (hr) packed = add8h(packed, rres[k]);
+            st16(Cb + (long long)row * p.ldc + cc * 8, packed);
+            if (EPI == 1 && p.stat_out != nullptr) {   // LN-fold producer: row statistics of the stored fp16 values
+                const half2v one2 = {(half_t)1.f, (half_t)1.f};
+                const half2v h0 = __builtin_bit_cast(half2v, packed.x), h1 = __builtin_bit_cast(half2v, packed.y);
+                const half2v h2 = __builtin_bit_cast(half2v, packed.z), h3 = __builtin_bit_cast(half2v, packed.w);
+                float a1 = __builtin_amdgcn_fdot2(h1, one2, __builtin_amdgcn_fdot2(h0, one2, 0.f, false), false);
+                float a2 = __builtin_amdgcn_fdot2(h1, h1, __builtin_amdgcn_fdot2(h0, h0, 0.f, false), false);
+                s1[k] = __builtin_amdgcn_fdot2(h3, one2, __builtin_amdgcn_fdot2(h2, one2, a1, false), false);
+                s2[k] = __builtin_amdgcn_fdot2(h3, h3, __builtin_amdgcn_fdot2(h2, h2, a2, false), false);
             }
         }
         if (EPI == 1 && p.stat_out != nullptr) {   // chunk partials -> LDS (the strip has been consumed) -> one lane per row, in chunk order
@@ -1327,6 +1318,12 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
     half_t* Cs = reinterpret_cast<half_t*>(smem5 + wid * 2 * V5_EPI_BYTES);
     const int part = tn_i * 2 + (wid & 1);                          // LN-fold statistics: one part per 160-column half tile
     const bool ln = LNC && p.ln_stat != nullptr;
+    // plain epilogues (no activation, no GEGLU): the bias is added HERE, in fp32 before the one rounding to fp16, and the strips add none
+    const bool bias_done = EPI != 2 && p.act == 0;
+    const bool add_b = bias_done && p.bias_n != nullptr;
+    // (always a load: an absent bias reads the zero page — a select around a load makes hipcc branch and wait per load; per strip, from L1 after
+    // the first: a batch held for all four strips costs 20 registers next to the 160 accumulators and spilled)
+    const half_t* bsrc = (add_b ? p.bias_n + n_w : reinterpret_cast<const half_t*>(g_zero_row)) + fq * 4;
     auto stage = [&](auto I, half_t* dst) {                         // literal strip index: the accumulators stay in registers
         constexpr int i = decltype(I)::value;
         // LN-fold consumer: acc <- rstd * (acc - mu * wsum) in fp32, strip by strip (keeps the live registers low)
@@ -1339,8 +1336,14 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
                 v = (v - mu * ws) * rs;
             }
             half4 h;
+            if constexpr (EPI != 2) {
+                const half4 bh = *reinterpret_cast<const half4*>(bsrc + j * 16);   // (L1-resident after the first strip)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)(v[r] * p.alpha);
+                for (int r = 0; r < 4; ++r) h[r] = (half_t)(v[r] * p.alpha + (float)bh[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (half_t)(v[r] * p.alpha);
+            }
             *reinterpret_cast<half4*>(dst + fr * V5_EPI_LD + j * 16 + fq * 4) = h;
         }
     };
@@ -1349,16 +1352,16 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
     stage(std::integral_constant<int, 1>{}, Cs1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: the strips are complete
     __builtin_amdgcn_sched_barrier(0);
-    v5_epilogue_strip<EPI>(p, Cs, z, m_w, n_w, lane, part);
-    v5_epilogue_strip<EPI>(p, Cs1, z, m_w + 16, n_w, lane, part);
+    v5_epilogue_strip<EPI>(p, Cs, z, m_w, n_w, lane, part, bias_done);
+    v5_epilogue_strip<EPI>(p, Cs1, z, m_w + 16, n_w, lane, part, bias_done);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // strips consumed before the next pair overwrites them
     __builtin_amdgcn_sched_barrier(0);
     stage(std::integral_constant<int, 2>{}, Cs);
     stage(std::integral_constant<int, 3>{}, Cs1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    v5_epilogue_strip<EPI>(p, Cs, z, m_w + 32, n_w, lane, part);
-    v5_epilogue_strip<EPI>(p, Cs1, z, m_w + 48, n_w, lane, part);
+    v5_epilogue_strip<EPI>(p, Cs, z, m_w + 32, n_w, lane, part, bias_done);
+    v5_epilogue_strip<EPI>(p, Cs1, z, m_w + 48, n_w, lane, part, bias_done);
 }
 
 // Epilogue of the halo-tile kernel's narrower tiles (256 x 256: the VAE's N = 256 / 512 convolutions; written for any width 16 TN per
