@@ -99,17 +99,17 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
     if (p.act == 2) {
         constexpr int CPR = BN / 16;
         constexpr int EIT = (BM * CPR + NT - 1) / NT;
-        if ((BM * CPR) % NT == 0 && m0 + BM <= p.M && n0 + BN <= p.N) {   // interior tile: branch-free, batched reads, interleaved erf-GELUs (common.h)
+        if ((BM * CPR) % NT == 0 && m0 + BM <= p.M && n0 + BN <= p.N && pre.bias_done) {
+            // interior tile: branch-free, batched reads, stage-by-stage GELUs (common.h) on the packed value chunk; the value / gate biases
+            // are in the staged tile already (accumulator start value / LayerNorm-fold finish), the residual is a packed fp16 add
             half_t* Cb = p.C + (long long)z * p.sC + (long long)m0 * p.ldc + n0 / 2;
             const bool hr = p.R != nullptr;
             const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m0 * p.ldr + n0 / 2 : nullptr;
-            uint4 rba[EIT], rbg[EIT], rres[EIT], ca[EIT], cg[EIT];
+            uint4 rres[EIT], ca[EIT], cg[EIT];
 #pragma unroll
             for (int it = 0; it < EIT; ++it) {
                 const int q = tid + it * NT;
                 const int row = q / CPR, cc = q - row * CPR;
-                rba[it] = ld16(bias_s + cc * 8);
-                rbg[it] = ld16(bias_s + cc * 8 + BN / 2);
                 rres[it] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
                 ca[it] = ld16(Cs + row * CLD + cc * 8);
                 cg[it] = ld16(Cs + row * CLD + BN / 2 + cc * 8);
@@ -118,25 +118,15 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
             for (int it = 0; it < EIT; ++it) {
                 const int q = tid + it * NT;
                 const int row = q / CPR, cc = q - row * CPR;
-                float a[8], g[8], ba[8], bg[8], r[8];
-                unpack8(ca[it], a);
+                float g[8];
                 unpack8(cg[it], g);
-                unpack8(rba[it], ba);
-                unpack8(rbg[it], bg);
-                unpack8(rres[it], r);
-                f32x2 ap[4], gp[4], op[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    ap[k] = (f32x2){a[2 * k] + ba[2 * k], a[2 * k + 1] + ba[2 * k + 1]};
-                    gp[k] = (f32x2){g[2 * k] + bg[2 * k], g[2 * k + 1] + bg[2 * k + 1]};
-                }
-                geglu8_staged_f32(ap, gp, op);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    a[2 * k] = op[k][0] + r[2 * k];
-                    a[2 * k + 1] = op[k][1] + r[2 * k + 1];
-                }
-                st16(Cb + (long long)row * p.ldc + cc * 8, pack8(a));
+                const unsigned aw[4] = {ca[it].x, ca[it].y, ca[it].z, ca[it].w};
+                const f32x2 gp[4] = {{g[0], g[1]}, {g[2], g[3]}, {g[4], g[5]}, {g[6], g[7]}};
+                unsigned ow[4];
+                geglu8_staged(aw, gp, ow);
+                uint4 packed = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                if (hr) packed = add8h(packed, rres[it]);
+                st16(Cb + (long long)row * p.ldc + cc * 8, packed);
             }
             return;
         }
@@ -147,8 +137,8 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
             const int row = q / CPR, cc = q - row * CPR;
             const int m = m0 + row, nv = n0 + cc * 8, ng = nv + BN / 2;
             const bool ok = q < BM * CPR && m < p.M && ng < p.N;
-            rba[it] = ok ? ld16(p.bias_n + nv) : zero16();
-            rbg[it] = ok ? ld16(p.bias_n + ng) : zero16();
+            rba[it] = (ok && !pre.bias_done) ? ld16(p.bias_n + nv) : zero16();
+            rbg[it] = (ok && !pre.bias_done) ? ld16(p.bias_n + ng) : zero16();
             rres[it] = (ok && p.R != nullptr) ? ld16(p.R + (long long)z * p.sR + (long long)m * p.ldr + n0 / 2 + cc * 8) : zero16();
         }
 #pragma unroll
@@ -649,10 +639,11 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
     wait_slab(kt_begin);
     __builtin_amdgcn_s_barrier();
     issue(kt_begin + PF, PF);
-    // the bias (zeros without one) is the accumulators' START value where the epilogue is a plain one (no activation, no split over K, no
-    // LayerNorm-fold finish, which adds it itself): the staged tile then holds acc * alpha + bias rounded ONCE, and the epilogue adds none
-    const bool bias_acc = splitk == 1 && p.ln_stat == nullptr && p.act == 0;
-    const bool bias_done = bias_acc || (splitk == 1 && p.ln_stat != nullptr && !p.ln_swapped && p.act == 0);
+    // the bias (zeros without one) is the accumulators' START value where the epilogue is a plain or a GEGLU one (no other activation, no
+    // split over K, no LayerNorm-fold finish, which adds it itself): the staged tile then holds acc * alpha + bias rounded ONCE, and the
+    // epilogue adds none
+    const bool bias_acc = splitk == 1 && p.ln_stat == nullptr && (p.act == 0 || p.act == 2);   // (GEGLU: value and gate biases alike, in the tile's column order)
+    const bool bias_done = bias_acc || (splitk == 1 && p.ln_stat != nullptr && !p.ln_swapped && (p.act == 0 || p.act == 2));
     if (bias_acc) {
         const float inv_alpha = 1.0f / p.alpha;
 #pragma unroll
@@ -728,10 +719,8 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = wn0 + j * 16 + fq * 4;
-            half4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] * p.alpha);
-            *reinterpret_cast<half4*>(Cs + ml * CLD + nl) = h;
+            const f32x4 v = acc[i][j] * p.alpha;
+            *reinterpret_cast<uint2*>(Cs + ml * CLD + nl) = make_uint2(pk2h(v[0], v[1]), pk2h(v[2], v[3]));
         }
     }
     __syncthreads();
@@ -970,8 +959,8 @@ __global__ __launch_bounds__(2 * NT, WPS) void gemm4_kernel(const GemmParams p) 
     };
     __builtin_amdgcn_s_barrier();                        // P
     // (bias as the accumulators' start value: see gemm3_kernel)
-    const bool bias_acc = splitk == 1 && p.ln_stat == nullptr && p.act == 0;
-    const bool bias_done = bias_acc || (splitk == 1 && p.ln_stat != nullptr && !p.ln_swapped && p.act == 0);
+    const bool bias_acc = splitk == 1 && p.ln_stat == nullptr && (p.act == 0 || p.act == 2);   // (GEGLU: value and gate biases alike, in the tile's column order)
+    const bool bias_done = bias_acc || (splitk == 1 && p.ln_stat != nullptr && !p.ln_swapped && (p.act == 0 || p.act == 2));
     if (bias_acc) {
         const float inv_alpha = 1.0f / p.alpha;
 #pragma unroll
@@ -1041,10 +1030,8 @@ __global__ __launch_bounds__(2 * NT, WPS) void gemm4_kernel(const GemmParams p) 
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = wn0 + j * 16 + fq * 4;
-            half4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] * p.alpha);
-            *reinterpret_cast<half4*>(Cs + ml * CLD + nl) = h;
+            const f32x4 v = acc[i][j] * p.alpha;
+            *reinterpret_cast<uint2*>(Cs + ml * CLD + nl) = make_uint2(pk2h(v[0], v[1]), pk2h(v[2], v[3]));
         }
     }
     __syncthreads();                                     // consumers only: the producers have exited
@@ -1095,14 +1082,13 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
             half_t* Cb = p.C + (long long)z * p.sC + (long long)m_base * p.ldc + n_base / 2;
             const bool hr = p.R != nullptr;
             const half_t* Rb = hr ? p.R + (long long)z * p.sR + (long long)m_base * p.ldr + n_base / 2 : nullptr;
-            uint4 rba[3], rbg[3], rres[3], ca[3], cg[3];
+            // (the value / gate biases are in the staged strip already: v5_finish adds them in fp32 before the rounding)
+            uint4 rres[3], ca[3], cg[3];
 #pragma unroll
             for (int it = 0; it < 3; ++it) {
                 const int q0 = lane + it * 64;
                 const int q = q0 < 160 ? q0 : 0;
                 const int row = q / 10, cc = q - row * 10;
-                rba[it] = ld16(p.bias_n + n_base + cc * 8);
-                rbg[it] = ld16(p.bias_n + n_base + cc * 8 + 80);
                 rres[it] = hr ? ld16(Rb + (long long)row * p.ldr + cc * 8) : zero16();
                 ca[it] = ld16(Cs + row * V5_EPI_LD + cc * 8);
                 cg[it] = ld16(Cs + row * V5_EPI_LD + 80 + cc * 8);
@@ -1112,25 +1098,15 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
                 const int q0 = lane + it * 64;
                 const int q = q0 < 160 ? q0 : 0;
                 const int row = q / 10, cc = q - row * 10;
-                float a[8], g[8], ba[8], bg[8], r[8];
-                unpack8(ca[it], a);
+                float g[8];
                 unpack8(cg[it], g);
-                unpack8(rba[it], ba);
-                unpack8(rbg[it], bg);
-                unpack8(rres[it], r);
-                f32x2 ap[4], gp[4], op[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    ap[k] = (f32x2){a[2 * k] + ba[2 * k], a[2 * k + 1] + ba[2 * k + 1]};
-                    gp[k] = (f32x2){g[2 * k] + bg[2 * k], g[2 * k + 1] + bg[2 * k + 1]};
-                }
-                geglu8_staged_f32(ap, gp, op);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    a[2 * k] = op[k][0] + r[2 * k];
-                    a[2 * k + 1] = op[k][1] + r[2 * k + 1];
-                }
-                if (q0 < 160) st16(Cb + (long long)row * p.ldc + cc * 8, pack8(a));
+                const unsigned aw[4] = {ca[it].x, ca[it].y, ca[it].z, ca[it].w};
+                const f32x2 gp[4] = {{g[0], g[1]}, {g[2], g[3]}, {g[4], g[5]}, {g[6], g[7]}};
+                unsigned ow[4];
+                geglu8_staged(aw, gp, ow);
+                uint4 packed = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                if (hr) packed = add8h(packed, rres[it]);
+                if (q0 < 160) st16(Cb + (long long)row * p.ldc + cc * 8, packed);
             }
             return;
         }
@@ -1141,8 +1117,8 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
             const int row = q / 10, cc = q - row * 10;
             const int m = m_base + row, nv = n_base + cc * 8;
             const bool ok = q < 160 && m < p.M;
-            rba[it] = ok ? ld16(p.bias_n + nv) : zero16();
-            rbg[it] = ok ? ld16(p.bias_n + nv + 80) : zero16();
+            rba[it] = (ok && !bias_done) ? ld16(p.bias_n + nv) : zero16();
+            rbg[it] = (ok && !bias_done) ? ld16(p.bias_n + nv + 80) : zero16();
             rres[it] = (ok && p.R != nullptr) ? ld16(p.R + (long long)z * p.sR + (long long)m * p.ldr + n_base / 2 + cc * 8) : zero16();
         }
 #pragma unroll
@@ -1318,8 +1294,8 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
     half_t* Cs = reinterpret_cast<half_t*>(smem5 + wid * 2 * V5_EPI_BYTES);
     const int part = tn_i * 2 + (wid & 1);                          // LN-fold statistics: one part per 160-column half tile
     const bool ln = LNC && p.ln_stat != nullptr;
-    // plain epilogues (no activation, no GEGLU): the bias is added HERE, in fp32 before the one rounding to fp16, and the strips add none
-    const bool bias_done = EPI != 2 && p.act == 0;
+    // plain epilogues (no activation) and GEGLU: the bias is added HERE, in fp32 before the one rounding to fp16, and the strips add none
+    const bool bias_done = EPI == 2 || p.act == 0;                 // (GEGLU: value and gate biases alike)
     const bool add_b = bias_done && p.bias_n != nullptr;
     // (always a load: an absent bias reads the zero page — a select around a load makes hipcc branch and wait per load; per strip, from L1 after
     // the first: a batch held for all four strips costs 20 registers next to the 160 accumulators and spilled)
@@ -1335,16 +1311,11 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
                 const f32x4 ws = *reinterpret_cast<const f32x4*>(p.ln_wsum + n_w + j * 16 + fq * 4);
                 v = (v - mu * ws) * rs;
             }
-            half4 h;
-            if constexpr (EPI != 2) {
-                const half4 bh = *reinterpret_cast<const half4*>(bsrc + j * 16);   // (L1-resident after the first strip)
+            const half4 bh = *reinterpret_cast<const half4*>(bsrc + j * 16);   // (L1-resident after the first strip; GEGLU: [80 value | 80 gate] biases, the strip's column order)
+            f32x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = (half_t)(v[r] * p.alpha + (float)bh[r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = (half_t)(v[r] * p.alpha);
-            }
-            *reinterpret_cast<half4*>(dst + fr * V5_EPI_LD + j * 16 + fq * 4) = h;
+            for (int r = 0; r < 4; ++r) o[r] = v[r] * p.alpha + (float)bh[r];
+            *reinterpret_cast<uint2*>(dst + fr * V5_EPI_LD + j * 16 + fq * 4) = make_uint2(pk2h(o[0], o[1]), pk2h(o[2], o[3]));
         }
     };
     half_t* Cs1 = Cs + 16 * V5_EPI_LD;
