@@ -627,6 +627,15 @@ __global__ __launch_bounds__(NT, NST == 2 ? 2 : 1) void gemm3_kernel(const GemmP
             else wait_vmcnt<0>();
         }
     };
+#ifdef LD_AB_BUILD
+    if ((p.dbg & 0x700) && NST == 2) {   // experiment (tools/gemm3_abl.py stagger): the second co-resident workgroup of a CU (the second 256 blocks) starts (dbg >> 8) & 7 us late
+        if ((int)blockIdx.x >= 256 && (int)blockIdx.x < 512) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long wait = 100ull * ((p.dbg >> 8) & 7);
+            while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+#endif
     f32x4 est_b, est_w;
     epi_stage_load<BN>(p, n0, tid, est_b, est_w);   // (before the first LDS-DMA: see epi_stage_load)
 #pragma unroll
@@ -1370,15 +1379,59 @@ __device__ __forceinline__ void v6_finish(const GemmParams& p, f32x4 (&acc)[TM][
     // (sum, sum of squares) of channels 0-3 / 4-7 apart when a group is 4 channels wide — and the tile's partials are put together below
     const bool gne = p.gn_part != nullptr, g4 = p.N == 128;
     float gs[4] = {0.f, 0.f, 0.f, 0.f};
+    // plain epilogues (no activation, no per-row bias): the bias is added HERE, in fp32 before the one rounding to fp16, and the strips work
+    // in packed fp16 (round 5, as v5_finish: the fp32 form cost ~70 vector instructions per 16-byte chunk — a quarter of the N = 128 convolutions'
+    // launch time at K = 1152)
+    const bool packed_ok = p.act == 0 && p.bias_m == nullptr;
+    const half_t* bsrc = ((packed_ok && hb) ? p.bias_n + n_w : reinterpret_cast<const half_t*>(g_zero_row)) + fq * 4;   // (always a load: zero page without a bias)
     auto stage = [&](auto I, half_t* dst) {
         constexpr int i = decltype(I)::value;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const f32x4 v = acc[i][j] * p.alpha;
+            const half4 bh = *reinterpret_cast<const half4*>(bsrc + j * 16);
+            f32x4 v = acc[i][j] * p.alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)bh[r];
             *reinterpret_cast<uint2*>(dst + fr * LD + j * 16 + fq * 4) = make_uint2(pk2h(v[0], v[1]), pk2h(v[2], v[3]));
         }
     };
     auto strip = [&](const half_t* Cs, int m_base) {
+        if (packed_ok) {
+            uint4 rv[ITS], rres[ITS], cv[ITS];
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) {
+                const int q0 = lane + it * 64;
+                const int q = (TOT % 64 == 0 || q0 < TOT) ? q0 : 0;
+                const int row = q / CPR, cc = q - row * CPR;
+                const int m = m_base + row < p.M ? m_base + row : p.M - 1;
+                const int n = n_w + cc * 8;
+                rv[it] = hv ? ld16(p.rowvec + (long long)(m / p.rows_per_vec) * p.ldrv + n) : zero16();
+                rres[it] = hr ? ld16(p.R + (long long)m * p.ldr + n) : zero16();
+                cv[it] = ld16(Cs + row * LD + cc * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < ITS; ++it) {
+                const int q0 = lane + it * 64;
+                const int q = (TOT % 64 == 0 || q0 < TOT) ? q0 : 0;
+                const int row = q / CPR, cc = q - row * CPR;
+                uint4 packed = cv[it];
+                if (hv) packed = add8h(packed, rv[it]);
+                if (hr) packed = add8h(packed, rres[it]);
+                if ((TOT % 64 == 0 || q0 < TOT) && m_base + row < p.M && n_w + cc * 8 < p.n_valid) {
+                    st16(p.C + (long long)(m_base + row) * p.ldc + n_w + cc * 8, packed);
+                    if (gne) {   // v_dot2_f32_f16 on the packed pairs: 8 instructions per chunk
+                        const half2v one2 = {(half_t)1.f, (half_t)1.f};
+                        const half2v h0 = __builtin_bit_cast(half2v, packed.x), h1 = __builtin_bit_cast(half2v, packed.y);
+                        const half2v h2 = __builtin_bit_cast(half2v, packed.z), h3 = __builtin_bit_cast(half2v, packed.w);
+                        gs[0] = __builtin_amdgcn_fdot2(h1, one2, __builtin_amdgcn_fdot2(h0, one2, gs[0], false), false);     // channels 0-3
+                        gs[1] = __builtin_amdgcn_fdot2(h1, h1, __builtin_amdgcn_fdot2(h0, h0, gs[1], false), false);
+                        gs[2] = __builtin_amdgcn_fdot2(h3, one2, __builtin_amdgcn_fdot2(h2, one2, gs[2], false), false);     // channels 4-7
+                        gs[3] = __builtin_amdgcn_fdot2(h3, h3, __builtin_amdgcn_fdot2(h2, h2, gs[3], false), false);
+                    }
+                }
+            }
+            return;
+        }
         uint4 rb[ITS], rv[ITS], rres[ITS], cv[ITS];
         half_t rm[ITS];
 #pragma unroll

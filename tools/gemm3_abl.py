@@ -20,7 +20,8 @@ def lin_nosplit(m, n, k, res=False):
 cases = [lin_nosplit(16384, 640, 640, True), lin_nosplit(4096, 1280, 1280, True), lin_nosplit(16384, 1920, 640), lin_nosplit(16384, 640, 3200, True), lin_nosplit(65536, 320, 1600, True)]
 names = {0: "baseline", 1: "no DMA behind the prologue", 2: "no fragment reads", 4: "no MFMAs", 7: "only barriers (+ epilogue)", 8: "no epilogue", 15: "prologue + barriers only",
          32: "no residual loads", 64: "no output stores", 96: "no residual loads, no stores", 103: "barriers + LDS staging of the tile only"}
-if len(sys.argv) > 1: names = {0: "baseline", 8: "no epilogue"}
+if len(sys.argv) > 1 and sys.argv[1] == "quick": names = {0: "baseline", 8: "no epilogue"}
+if len(sys.argv) > 1 and sys.argv[1] == "stagger": names = {0: "baseline", 0x100: "second 256 blocks 1 us late", 0x200: "2 us late", 0x300: "3 us late", 0x400: "4 us late", 0x500: "5 us late", 0x600: "6 us late"}
 for fn, fl, name in cases:
     print(name)
     for bits, what in names.items():
