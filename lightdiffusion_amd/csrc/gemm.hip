@@ -2062,32 +2062,42 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
     const int NS = p.N / V7_NB;                                         // steps (80 W rows each)
 
     // ---- A fragments: rows mw + 16 i + fr, k = 32 ks + 8 fq .. + 7 (rows past M are clamped; their outputs are never stored)
+    // Round 5: requested in the prologue BEHIND the first W pieces and in k-step order, and not waited for there (the prologue's counted wait
+    // leaves these 20 loads in flight): the first step's MFMAs start on k-step 0 while the later k-steps of the 164 KB panel are still
+    // arriving — before, every workgroup sat through its whole panel load (all 256 at once: ~7 of a 32 us launch) before its first MFMA.
     half8 fa[TM][V7_KS];
+    auto load_a = [&]() {
+        const half_t* ar[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = mw + i * 16 + fr;
-        const half_t* ar = p.A + (long long)(m < p.M ? m : p.M - 1) * p.lda + fq * 8;
+        for (int i = 0; i < TM; ++i) {
+            const int m = mw + i * 16 + fr;
+            ar[i] = p.A + (long long)(m < p.M ? m : p.M - 1) * p.lda + fq * 8;
+        }
 #pragma unroll
-        for (int ks = 0; ks < V7_KS; ++ks) fa[i][ks] = as_half8(ld16(ar + ks * 32));
-    }
+        for (int ks = 0; ks < V7_KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i][ks] = as_half8(ld16(ar[i] + ks * 32));
+    };
     // ---- LayerNorm fold (consumer): (mu, rstd) of my rows from the producer's per-part (sum, sum of squares).  The whole affine part of
     // the epilogue,  v = rstd alpha (acc - mu wsum) + bias,  is folded into the accumulators' START value  bias / (rstd alpha) - mu wsum
     // (set at the head of a step's MFMA phase, which has vector-issue slack), so the epilogue is one multiply by rstd alpha.
     float rs_a[TM], inv_a[TM], mu_a[TM];
+    auto ln_fill = [&]() {   // (prologue, behind the first W pieces: its loads are waited for at once — together with those pieces, which the prologue needs anyway)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        rs_a[i] = p.alpha;
-        mu_a[i] = 0.f;
-        if (LN) {
-            const int m = mw + i * 16 + fr;
-            float s1 = 0.f, s2 = 0.f;
-            if (m < p.M) ln_sum_parts(p.ln_stat + (long long)m * 2, (long long)p.ln_rows * 2, p.ln_parts, s1, s2);
-            const float mu = s1 * p.ln_inv_c;
-            mu_a[i] = mu;
-            rs_a[i] = rsqrtf(fmaxf(s2 * p.ln_inv_c - mu * mu, 0.f) + p.ln_eps) * p.alpha;     // (rows past M: finite garbage, never stored)
+        for (int i = 0; i < TM; ++i) {
+            rs_a[i] = p.alpha;
+            mu_a[i] = 0.f;
+            if (LN) {
+                const int m = mw + i * 16 + fr;
+                float s1 = 0.f, s2 = 0.f;
+                if (m < p.M) ln_sum_parts(p.ln_stat + (long long)m * 2, (long long)p.ln_rows * 2, p.ln_parts, s1, s2);
+                const float mu = s1 * p.ln_inv_c;
+                mu_a[i] = mu;
+                rs_a[i] = rsqrtf(fmaxf(s2 * p.ln_inv_c - mu * mu, 0.f) + p.ln_eps) * p.alpha;     // (rows past M: finite garbage, never stored)
+            }
+            inv_a[i] = 1.0f / rs_a[i];
         }
-        inv_a[i] = 1.0f / rs_a[i];
-    }
+    };
     auto key = [](int r) { return (r & 3) | (((r >> 3) & 1) << 2); };
     // ---- W loader: piece (wid + 8 i) of a stage, lane l -> LDS byte o = piece * 1024 + 16 l -> row o / 640, physical chunk (o % 640) / 16
     unsigned w_off[7];
@@ -2357,8 +2367,10 @@ __global__ __launch_bounds__(512, 2) void gemm7_kernel(const GemmParams p) {
     // ---- prologue: step 0 (everyone) and group 1's share of step 1 in flight; step 0 landed and published; group 1 one barrier behind
     issue();
     if (grp1 && NS > 1) issue();
-    if (grp1 && NS > 1) wait_vmcnt<7>();
-    else wait_vmcnt<0>();
+    ln_fill();
+    load_a();
+    // every W piece issued above (and the LayerNorm statistics) is older than the TM * V7_KS loads of the A panel: this leaves exactly those in flight
+    wait_vmcnt<TM * V7_KS>();
     __builtin_amdgcn_s_barrier();
     if (grp1) __builtin_amdgcn_s_barrier();
     int st = 0;

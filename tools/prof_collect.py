@@ -14,9 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short_name(k):
     k = k.replace("(anonymous namespace)::", "").replace("void ", "")
-    m = re.match(r"gemm(\d)_kernel<(\d+), (\d+), (true|false)(?:, \d+)?>", k)
-    if m:
-        return f"gemm{m.group(1)}_kernel<{m.group(2)},{m.group(3)},{'conv' if m.group(4) == 'true' else 'plain'}>"
+    m = re.match(r"gemm(\d)_kernel<(\d+), (\d+), (true|false)(?:, (\d+))?(?:, (\d+))?>", k)
+    if m:   # (gemm4's trailing parameters: ring depth, waves per SIMD — 4 = the two-workgroups-per-CU instantiation gemm_launch names ",2wg")
+        two = m.group(1) == "4" and m.group(6) == "4"
+        return f"gemm{m.group(1)}_kernel<{m.group(2)},{m.group(3)},{'conv' if m.group(4) == 'true' else 'plain'}{',2wg' if two else ''}>"
     m = re.match(r"gemm5_kernel<(true|false)(?:, \d+)?>", k)
     if m:
         return f"gemm5_kernel<256,320,{'conv' if m.group(1) == 'true' else 'plain'}>"
