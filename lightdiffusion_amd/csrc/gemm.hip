@@ -2566,6 +2566,7 @@ const char* intern_name(const std::string& s) {   // stable storage for composed
 }
 
 static bool two_wg_ok();   // (A/B hook, below)
+static bool m_fastest_ok();
 
 template <int BM, int BN>
 void launch_cfg(const GemmParams& p, hipStream_t s, bool deep = false) {
@@ -2629,6 +2630,13 @@ extern "C" void ld_debug_gemm_v5_dbg(int bits) { g_v5_dbg = bits; }   // 1: no D
 #endif
 
 namespace {
+bool m_fastest_ok() {
+#ifdef LD_AB_BUILD
+    return (g_no_v5 & 4096) == 0;    // A/B: bit 4096 keeps the N-fastest tile order everywhere
+#else
+    return true;
+#endif
+}
 bool two_wg_ok() {
 #ifdef LD_AB_BUILD
     return (g_no_v5 & 2048) == 0;    // A/B: bit 2048 keeps round 4's 2-stage kernel for the 64 x 64 tiles beyond 256 workgroups
@@ -3030,7 +3038,13 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     p.bn = bn;
     // measured (profiles/r01_b): n-fastest wins on every SD1.5 shape — the 9 taps of a 3x3 conv and the N tiles of one
     // M panel re-read the same activations through the XCD's L2, which matters more than re-streaming the weights
-    if (p.m_fastest < 0) p.m_fastest = 0;
+    // Round 5: a plain GEMM with few M panels and a large weight matrix (the batch-1 step's M = 512 GEGLU: 4 panels x 26 MB) walks its tiles
+    // M-fastest, so the panels of one N tile run together on one XCD and the weight tile leaves HBM once instead of once per panel
+    // (profiles/pmc_traffic.json round 4: 113 MB per launch for 26 MB of weights)
+    if (p.m_fastest < 0) {
+        const int tiles_m = (p.M + bm - 1) / bm;
+        p.m_fastest = (!p.conv && p.batch == 1 && tiles_m >= 2 && tiles_m <= 8 && (long long)p.N * p.K * 2 >= (8ll << 20) && m_fastest_ok()) ? 1 : 0;
+    }
 
     if (bn == 64) launch_cfg<64, 64>(p, stream);
     else if (bm == 128 && bn == 160) launch_cfg<128, 160>(p, stream);
