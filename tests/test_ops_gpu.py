@@ -376,6 +376,24 @@ def test_linear_ln_big_tiles(ops):
     assert rel_l2(y.float().cpu(), y_ref.cpu()) < 3e-3
 
 
+# The batch-1 step's transformer projections as the executor runs them (LayerNorm fold: no split over K): producer t = x Wp^T + bp with row
+# statistics, consumer y = LN(t) W^T + b finished on the accumulators (the bias is added by that finish, round 5).  M = 2048, C = 640: 320
+# tiles of 64 x 64 -> the producer / consumer kernel with two workgroups per CU; M = 512, C = 1280, N = 3840: four M panels x 9.8 MB of
+# weights -> the M-fastest tile order; M = 8192, C = 320: the 2-stage 64 x 64 kernel.
+@pytest.mark.parametrize("M,C,N", [(2048, 640, 640), (2048, 640, 1920), (512, 1280, 1280), (512, 1280, 3840), (8192, 320, 960), (128, 1280, 1280)])
+def test_linear_ln_batch1_shapes(ops, M, C, N):
+    g = torch.Generator().manual_seed(197)
+    x = (torch.randn(M, C, generator=g) * 2.0 + 0.7).half()
+    wp, bp = (torch.randn(C, C, generator=g) / math.sqrt(C)).half(), (0.1 * torch.randn(C, generator=g)).half()
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).half(), (0.1 * torch.randn(C, generator=g)).half()
+    w, b = (torch.randn(N, C, generator=g) / math.sqrt(C)).half(), (0.3 * torch.randn(N, generator=g)).half()
+    t, y = ops.linear_ln(x.to(DEV), wp.to(DEV), bp.to(DEV), gamma.to(DEV), beta.to(DEV), w.to(DEV), b.to(DEV))
+    t_ref = F.linear(x.float(), wp.float(), bp.float())
+    assert rel_l2(t.float().cpu(), t_ref) < TOL
+    y_ref = F.linear(F.layer_norm(t.float().cpu(), (C,), gamma.float(), beta.float(), 1e-5), w.float(), b.float())
+    assert rel_l2(y.float().cpu(), y_ref) < 3e-3
+
+
 @pytest.mark.parametrize("n,h,w,c1,c2,cout,rv,res", [
     (16, 64, 64, 320, 0, 320, True, False),      # fused into the halo kernel (W = 64), the level-0 ResBlock in_layers
     (16, 64, 64, 640, 320, 320, True, True),     # fused, two sources: groups of 30 channels straddle the 8-channel chunks AND the source boundary
