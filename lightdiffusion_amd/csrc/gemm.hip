@@ -1281,6 +1281,9 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
     constexpr int TM = 4, TN = 10;
     const int fr = lane & 15, fq = lane >> 4;
     const int m_w = m0 + wm0, n_w = n0 + wn0;
+#ifdef LD_AB_BUILD
+    if (p.dbg & 4096) return;                                       // ablation (tools/conv6_abl.py; wrong results, timing only): no epilogue
+#endif
     if (splitk > 1) {
         float* part = p.partial + (long long)ks * p.M * p.N;
 #pragma unroll
@@ -2567,6 +2570,7 @@ const char* intern_name(const std::string& s) {   // stable storage for composed
 
 static bool two_wg_ok();   // (A/B hook, below)
 static bool m_fastest_ok();
+static bool skinny_conv1_ok();
 
 template <int BM, int BN>
 void launch_cfg(const GemmParams& p, hipStream_t s, bool deep = false) {
@@ -2585,6 +2589,11 @@ void launch_cfg(const GemmParams& p, hipStream_t s, bool deep = false) {
         if (!p.conv && two_wg_ok() && blocks > V4_MAX_BLOCKS && blocks <= 512 && p.K >= 640) {
             t_last_kernel = "gemm4_kernel<64,64,plain,2wg>";
             hipLaunchKernelGGL((gemm4_kernel<64, 64, false, 4, 4>), grid, dim3(2 * NT), 0, s, p);
+            return;
+        }
+        if (p.conv && p.ksize == 1 && sk == 1 && blocks <= 512) {   // (gemm_launch's skinny_conv1 rule)
+            t_last_kernel = "gemm4_kernel<64,64,conv,2wg>";
+            hipLaunchKernelGGL((gemm4_kernel<64, 64, true, 4, 4>), grid, dim3(2 * NT), 0, s, p);
             return;
         }
     }
@@ -2630,6 +2639,13 @@ extern "C" void ld_debug_gemm_v5_dbg(int bits) { g_v5_dbg = bits; }   // 1: no D
 #endif
 
 namespace {
+bool skinny_conv1_ok() {
+#ifdef LD_AB_BUILD
+    return (g_no_v5 & 8192) == 0;    // A/B: bit 8192 keeps the split 64 x 160 tiles for the skinny 1x1 convolutions
+#else
+    return true;
+#endif
+}
 bool m_fastest_ok() {
 #ifdef LD_AB_BUILD
     return (g_no_v5 & 4096) == 0;    // A/B: bit 4096 keeps the N-fastest tile order everywhere
@@ -2985,6 +3001,20 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         const long long t160 = (long long)((p.M + 63) / 64) * ((p.N + bn - 1) / bn) * p.batch;
         if (t160 <= skinny_max && (p.N + bn - 1) / bn <= 8) bn = 64;      // (wide outputs keep the 160-column tile: 512 x 2560 x 1280 -9 % in the forward)
     }
+    // Round 5: the batch-1 step's 1x1 contractions over two sources (ResBlock skip_connection on the concatenated input, the MLP-out fold at
+    // K = 3200) take the same 64 x 64 tiles UNSPLIT on the producer / consumer kernel with two workgroups per CU, instead of 64 x 160 tiles
+    // split over K + a reduce launch.  Per shape inside the batch-1 forward (tools/ab_launches.py 1 0 8192, profiles/r05_ab_skinny_conv1.txt):
+    // 2048 x 640 x 3200 32.2 -> 27.7 us, 2048 x 640 x 1920 26.1 -> 19.4, 512 x 1280 x 2560 25.3 -> 21.4; K = 6400 (100 slabs in one
+    // workgroup) loses: 31.8 -> 37.1 us, so K stops at 3200.  (Without a split there are no GroupNorm partials from the reduce pass: the next
+    // GroupNorm runs its own statistics pass — counted in the whole-forward A/B: 5.225 -> 5.207 ms before K was capped.)
+    bool skinny_conv1 = false;
+    if (skinny_conv1_ok() && p.conv && p.ksize == 1 && p.act == 0 && p.bn == 0 && p.bm == 0 && p.splitk == 0 && p.batch == 1 && (p.N % 64) == 0 && p.SC1 == 0) {
+        const long long t64 = (long long)((p.M + 63) / 64) * (p.N / 64);
+        if (t64 > 128 && t64 <= 512 && p.K >= 1280 && p.K <= 3200) {
+            bn = 64;
+            skinny_conv1 = true;
+        }
+    }
     if (bn != 128 && bn != 160 && bn != 64) return LD_ERR_ARG;
     if (p.act == 2 && (p.N % bn)) return LD_ERR_SHAPE;
     const int tiles_n = (p.N + bn - 1) / bn;
@@ -3007,6 +3037,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         else bm = 64;
     }
     if (bn == 64) bm = 64;
+    if (skinny_conv1) sk = 1;
     if (bm != 64 && bm != 128) return LD_ERR_ARG;
     const int tiles = ((p.M + bm - 1) / bm) * tiles_n;
     // Convolutions on 64 x 160 tiles with very few tiles (<= 32: the 8 x 8 level of a batch-1 step) or exactly one round of them (256 .. 511)

@@ -103,6 +103,20 @@ def test_conv1x1_concat(ops):
     assert rel_l2(nchw(y.float().cpu()), ref) < TOL
 
 
+# 1x1 convolutions over two concatenated sources at the batch-1 step's sizes (ResBlock skip_connection, LD.py:5267, on th.cat([h, skip])):
+# 64 x 64 tiles, unsplit, on the producer / consumer kernel's implicit-im2col instantiation with two workgroups per CU (round 5)
+@pytest.mark.parametrize("n,hw,c1,c2,cout,res", [(2, 32, 1280, 640, 640, False), (2, 32, 640, 640, 640, True), (2, 16, 1280, 1280, 1280, False), (2, 16, 1280, 640, 1280, True)])
+def test_conv1x1_two_sources_skinny(ops, n, hw, c1, c2, cout, res):
+    x1, x2 = r16((n, c1, hw, hw), 311), r16((n, c2, hw, hw), 312) - 0.5
+    wt, b = r16((cout, c1 + c2, 1, 1), 313, 1 / math.sqrt(c1 + c2)), r16((cout,), 314, 0.2)
+    r = r16((n, cout, hw, hw), 315) if res else None
+    ref = F.conv2d(torch.cat([x1.float(), x2.float()], 1).to(DEV), wt.float().to(DEV), b.float().to(DEV))
+    if res:
+        ref = ref + r.float().to(DEV)
+    y = ops.conv2d(nhwc(x1).to(DEV), ops.repack_conv_weight(wt.to(DEV)), b.to(DEV), 1, 1, nhwc(x2).to(DEV), None, None, None if r is None else nhwc(r).to(DEV))
+    assert rel_l2(nchw(y.float().cpu()), ref.cpu()) < TOL
+
+
 def test_block_goldens_via_ops(ops):
     """ResBlock1 / Downsample1 / Upsample1 of the reference (goldens) rebuilt from the operator seam."""
     for tag, cin, cout in (("res_skip", 64, 128), ("res_id", 64, 64)):
