@@ -3005,7 +3005,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
     // K = 3200) take the same 64 x 64 tiles UNSPLIT on the producer / consumer kernel with two workgroups per CU, instead of 64 x 160 tiles
     // split over K + a reduce launch.  Per shape inside the batch-1 forward (tools/ab_launches.py 1 0 8192, profiles/r05_ab_skinny_conv1.txt):
     // 2048 x 640 x 3200 32.2 -> 27.7 us, 2048 x 640 x 1920 26.1 -> 19.4, 512 x 1280 x 2560 25.3 -> 21.4; K = 6400 (100 slabs in one
-    // workgroup) loses: 31.8 -> 37.1 us, so K stops at 3200.  (Without a split there are no GroupNorm partials from the reduce pass: the next
+    // workgroup) loses: 31.8 -> 37.1 us, and as two slices of 3200 + reduce 31.5 -> 34.4 us, so K stops at 3200.  (Without a split there are no GroupNorm partials from the reduce pass: the next
     // GroupNorm runs its own statistics pass — counted in the whole-forward A/B: 5.225 -> 5.207 ms before K was capped.)
     bool skinny_conv1 = false;
     if (skinny_conv1_ok() && p.conv && p.ksize == 1 && p.act == 0 && p.bn == 0 && p.bm == 0 && p.splitk == 0 && p.batch == 1 && (p.N % 64) == 0 && p.SC1 == 0) {
@@ -3014,6 +3014,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
             bn = 64;
             skinny_conv1 = true;
         }
+
     }
     if (bn != 128 && bn != 160 && bn != 64) return LD_ERR_ARG;
     if (p.act == 2 && (p.N % bn)) return LD_ERR_SHAPE;
