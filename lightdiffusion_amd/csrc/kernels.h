@@ -66,6 +66,7 @@ struct SmallConvInArgs {        // 3x3 pad-1 conv with <= 4 input channels from 
     const half_t* b = nullptr;
     half_t* y = nullptr;        // NHWC [N][H][W][Cout]
     int N = 0, Cin = 0, H = 0, W = 0, Cout = 0;
+    long long dup_off = 0;      // != 0: every output chunk is stored a second time at y + dup_off (elements): the second half of a CFG pair (unet.hip)
 };
 int small_conv_in_launch(const SmallConvInArgs& a, hipStream_t stream);
 
@@ -80,6 +81,7 @@ struct SmallConvOutArgs {       // 3x3 pad-1 conv to <= 4 output channels from a
     const float* x_in = nullptr;   // mode 0: [N][Cout][H][W] fp32
     const float* sigma = nullptr;  // mode 0: [N]
     float* out = nullptr;
+    int in_mod = 0;                // > 0: x_in / sigma hold in_mod samples and sample n reads n % in_mod (CFG pair: both halves see the same latents)
 };
 int small_conv_out_launch(const SmallConvOutArgs& a, hipStream_t stream);
 
@@ -90,8 +92,17 @@ int vae_out_finish_launch(const half_t* t8, float* out, long long npix, int cout
 int small_pointwise_launch(const half_t* x, const half_t* w, const half_t* b, float* out, int N, int HW, int C, hipStream_t stream);
 
 // timestep lookup + sinusoidal embedding: sigma[N] -> t = argmin |log sigma - log_sigmas| -> [N][dim] fp16 (cos | sin)
+// sigma_mod > 0: sigma holds sigma_mod samples and sample n reads sigma[n % sigma_mod] (CFG pair)
 int timestep_embed_launch(const float* sigma, const float* log_sigmas, int n_sig, int N, int dim, half_t* out, float* t_out,
-                          hipStream_t stream);
+                          hipStream_t stream, int sigma_mod = 0);
+
+// up to three ranges [base, base + bytes) copied to [base + bytes, base + 2 bytes) in one launch (the hand-over of a CFG pair's shared prefix, unet.hip)
+struct DupArgs {
+    char* base[3] = {nullptr, nullptr, nullptr};
+    unsigned long long bytes[3] = {0, 0, 0};   // multiples of 16
+    int count = 0;
+};
+int dup_halves_launch(const DupArgs& a, hipStream_t stream);
 
 // weight repack (device side, run once at load)
 int repack_conv3x3_launch(const void* src, int src_is_f32, int O, int I, half_t* dst, hipStream_t stream);  // OIHW -> [O][ky][kx][I]

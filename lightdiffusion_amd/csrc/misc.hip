@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256) void small_conv_in_kernel(const SmallConvInArg
                 }
             }
         }
-        st16(a.y + (((long long)n * a.H + y) * a.W + x) * a.Cout + cg * 8, pack8(acc));
+        const long long o = (((long long)n * a.H + y) * a.W + x) * a.Cout + cg * 8;
+        const uint4 v8 = pack8(acc);
+        st16(a.y + o, v8);
+        if (a.dup_off != 0) st16(a.y + a.dup_off + o, v8);
     }
 }
 
@@ -163,7 +166,8 @@ __global__ __launch_bounds__(256) void small_conv_out_kernel(const SmallConvOutA
                 const long long nchw = (((long long)n * a.Cout + o) * a.H + y) * a.W + x;
                 if (a.mode == 0) {
                     const float eps = (float)(half_t)v;   // the reference's UNet output is an fp16 tensor (.float() after)
-                    a.out[nchw] = a.x_in[nchw] - eps * a.sigma[n];
+                    const int ni = a.in_mod > 0 ? n % a.in_mod : n;
+                    a.out[nchw] = a.x_in[(((long long)ni * a.Cout + o) * a.H + y) * a.W + x] - eps * a.sigma[ni];
                 } else if (a.mode == 1) {
                     a.out[pix * a.Cout + o] = fminf(fmaxf((v + 1.0f) * 0.5f, 0.f), 1.f);
                 } else {
@@ -202,11 +206,11 @@ __global__ void vae_out_finish_kernel(const half_t* __restrict__ t8, float* __re
 // ------------------------------------------------------------------------------------------------ timestep embedding
 // ModelSamplingDiscrete.timestep (LD.py:1336-1339) + timestep_embedding (LD.py:803-812).  One block per sample.
 __global__ __launch_bounds__(256) void timestep_embed_kernel(const float* sigma, const float* log_sigmas, int n_sig, int dim,
-                                                             half_t* out, float* t_out) {
+                                                             half_t* out, float* t_out, int sigma_mod) {
     __shared__ float bd[256];
     __shared__ int bi[256];
     const int n = blockIdx.x, tid = threadIdx.x;
-    const float ls = logf(sigma[n]);
+    const float ls = logf(sigma[sigma_mod > 0 ? n % sigma_mod : n]);
     float best = INFINITY;
     int besti = 0;
     for (int i = tid; i < n_sig; i += 256) {
@@ -237,6 +241,32 @@ __global__ __launch_bounds__(256) void timestep_embed_kernel(const float* sigma,
         const float arg = t * f;
         out[(long long)n * dim + i] = (half_t)cosf(arg);
         out[(long long)n * dim + half_dim + i] = (half_t)sinf(arg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ CFG pair hand-over
+// each range's first half -> its second half, 16 bytes per lane and four of them in flight (one launch instead of one copy node per range)
+__global__ __launch_bounds__(256) void dup_halves_kernel(const DupArgs a) {
+    const unsigned long long c0 = a.bytes[0] / 16, c1 = c0 + (a.count > 1 ? a.bytes[1] / 16 : 0), c2 = c1 + (a.count > 2 ? a.bytes[2] / 16 : 0);
+    const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < c2; q += 4 * step) {
+        uint4 v[4];
+        char* dst[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned long long i = q + e * step;
+            dst[e] = nullptr;
+            if (i < c2) {
+                const int r = i < c0 ? 0 : (i < c1 ? 1 : 2);
+                const unsigned long long j = i - (r == 0 ? 0 : (r == 1 ? c0 : c1));
+                const char* src = a.base[r] + j * 16;
+                v[e] = *reinterpret_cast<const uint4*>(src);
+                dst[e] = a.base[r] + a.bytes[r] + j * 16;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (dst[e] != nullptr) *reinterpret_cast<uint4*>(dst[e]) = v[e];
     }
 }
 
@@ -357,9 +387,21 @@ int small_pointwise_launch(const half_t* x, const half_t* w, const half_t* b, fl
 }
 
 int timestep_embed_launch(const float* sigma, const float* log_sigmas, int n_sig, int N, int dim, half_t* out, float* t_out,
-                          hipStream_t stream) {
-    if (sigma == nullptr || log_sigmas == nullptr || out == nullptr || N <= 0 || (dim & 1)) return LD_ERR_ARG;
-    hipLaunchKernelGGL(timestep_embed_kernel, dim3(N), dim3(256), 0, stream, sigma, log_sigmas, n_sig, dim, out, t_out);
+                          hipStream_t stream, int sigma_mod) {
+    if (sigma == nullptr || log_sigmas == nullptr || out == nullptr || N <= 0 || (dim & 1) || sigma_mod < 0) return LD_ERR_ARG;
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(N), dim3(256), 0, stream, sigma, log_sigmas, n_sig, dim, out, t_out, sigma_mod);
+    return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+}
+
+int dup_halves_launch(const DupArgs& a, hipStream_t stream) {
+    if (a.count < 1 || a.count > 3) return LD_ERR_ARG;
+    unsigned long long total = 0;
+    for (int i = 0; i < a.count; ++i) {
+        if (a.base[i] == nullptr || (a.bytes[i] & 15) || (reinterpret_cast<uintptr_t>(a.base[i]) & 15)) return LD_ERR_ARG;
+        total += a.bytes[i] / 16;
+    }
+    if (total == 0) return LD_OK;
+    hipLaunchKernelGGL(dup_halves_kernel, dim3(grid_for((long long)((total + 3) / 4), 256, 2048)), dim3(256), 0, stream, a);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
 

@@ -286,7 +286,7 @@ struct Run {
     const half_t* emb_all;   // [n_alloc][emb_total]
     half_t* P(int slot) const { return u->pt.ptr(slot); }
     int na() const { return n_alloc > 0 ? n_alloc : n; }
-    // first half of a [2 * half_bytes] tensor -> its second half (a memcpy node of the step's hipGraph)
+    // first half of a [2 * half_bytes] tensor -> its second half (a memcpy node of the step's hipGraph; layouts other than SD1.5's, whose hand-over is one dup_halves launch)
     void dup(void* base, size_t half_bytes) {
         ex.launches += 1;
         ex.t_begin(KC_MISC, 0.0, 1, "dup", (long long)half_bytes, 0, 0, 1);
@@ -509,9 +509,14 @@ struct Run {
         }
         if (split_here) {
             const size_t hb = (size_t)M * C * sizeof(half_t);
-            dup(t, hb);
-            dup(q2, hb);
-            dup(const_cast<half_t*>(x), hb);
+            DupArgs da;
+            da.count = 3;
+            da.base[0] = reinterpret_cast<char*>(t); da.base[1] = reinterpret_cast<char*>(q2); da.base[2] = reinterpret_cast<char*>(const_cast<half_t*>(x));
+            da.bytes[0] = da.bytes[1] = da.bytes[2] = hb;
+            ex.launches += 1;
+            ex.t_begin(KC_MISC, 0.0, 1, "dup3", (long long)hb, 0, 0, 1);
+            if (!ex.dry && ex.status == LD_OK) ex.note(dup_halves_launch(da, ex.stream));
+            ex.t_end("dup_halves_kernel");
             pair_pending = false;
             n = n_alloc;
             M = n * L;
@@ -642,30 +647,14 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
     ar.release(0);
     const ld_unet_config& c = u->cfg;
     const int mc = c.model_channels, ted = u->ted;
-    if (pair) {
-        // both halves of the inputs side by side (the output convolution and the time embedding index them by sample): 2 x 2 small copies
-        const int nb = n / 2;
-        float* x2 = reinterpret_cast<float*>(ar.alloc((size_t)n * c.in_channels * h * w * sizeof(float)));
-        float* s2 = reinterpret_cast<float*>(ar.alloc((size_t)n * sizeof(float)));
-        const size_t xb = (size_t)nb * c.in_channels * h * w * sizeof(float), sb = (size_t)nb * sizeof(float);
-        ex.launches += 2;
-        ex.t_begin(KC_MISC, 0.0, 2, "dup_in", (long long)xb, 0, 0, 1);
-        if (!dry && (hipMemcpyAsync(x2, x, xb, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
-                     hipMemcpyAsync(s2, sigma, sb, hipMemcpyDeviceToDevice, stream) != hipSuccess))
-            ex.note(LD_ERR_HIP);
-        ex.t_end("hipMemcpyAsync(pair)");
-        R.dup(x2, xb);
-        R.dup(s2, sb);
-        x = x2;
-        sigma = s2;
-        R.pair_pending = true;
-    }
+    const int in_mod = pair ? n / 2 : 0;   // CFG pair: x / sigma hold n / 2 samples; the kernels that read them per sample index n % in_mod
+    if (pair) R.pair_pending = true;
 
     // timestep embedding -> time_embed MLP -> all ResBlock emb_layers at once (every consumer applies SiLU first)
     half_t* temb = ar.halfs((size_t)n * mc);
     ex.launches += 1;
     ex.t_begin(KC_MISC, 0.0, 1);
-    if (!dry) ex.note(timestep_embed_launch(sigma, u->log_sigmas, 1000, n, mc, temb, nullptr, stream));
+    if (!dry) ex.note(timestep_embed_launch(sigma, u->log_sigmas, 1000, n, mc, temb, nullptr, stream, in_mod));
     ex.t_end("timestep_embed_kernel");
     half_t* e1 = ar.halfs((size_t)n * ted);
     R.linear(temb, mc, u->te0_w, u->te0_b, nullptr, e1, n, ted, mc, 1);
@@ -723,12 +712,12 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
         SmallConvInArgs a;
         a.x = x; a.scale_sigma = sigma; a.w = u->pt.ptr(cw.w); a.b = u->pt.ptr(cw.b); a.y = o;
         a.N = R.n; a.Cin = c.in_channels; a.H = h; a.W = w; a.Cout = mc;
+        if (R.pair_pending) a.dup_off = (long long)R.n * h * w * mc;   // a skip connection: read by the last output block on all n samples
         ex.launches += 1;
         ex.flops += 2.0 * R.n * h * w * mc * 9.0 * c.in_channels;
         ex.t_begin(KC_MISC, 2.0 * R.n * h * w * mc * 9.0 * c.in_channels, 1);
         if (!dry) ex.note(small_conv_in_launch(a, stream));
         ex.t_end("small_conv_in_kernel");
-        if (R.pair_pending) R.dup(o, (size_t)R.n * h * w * mc * sizeof(half_t));   // a skip connection: read by the last output block on all n samples
         f = {o, mc, h, w};
         hs.push_back(f);
     }
@@ -762,7 +751,7 @@ int run_forward(ld_unet* u, bool dry, const float* x, const float* sigma, float*
         a.x = g; a.w = u->pt.ptr(u->outc_w); a.b = u->pt.ptr(u->outc_b);
         a.N = n; a.H = f.H; a.W = f.W; a.Cin = f.C; a.Cout = c.out_channels;
         a.mode = eps_only ? 2 : 0;
-        a.x_in = x; a.sigma = sigma; a.out = out;
+        a.x_in = x; a.sigma = sigma; a.out = out; a.in_mod = in_mod;
         ex.launches += 1;
         ex.flops += 2.0 * n * f.H * f.W * f.C * 9.0 * c.out_channels;
         ex.t_begin(KC_MISC, 2.0 * n * f.H * f.W * f.C * 9.0 * c.out_channels, 1);
