@@ -1788,7 +1788,8 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     constexpr int TM = BM / 64, TN = BN / 32;
     static_assert(BN == 320 || BN == 256 || BN == 160 || BN == 128 || BN == 32, "tile width");
     static_assert(BM == 256 || (BM == 512 && W == 128), "tile height: 256 pixels, or four rows of a 128-pixel band");
-    static_assert(!GN || BN == V5_BN, "the fused GroupNorm only pays where the output is one 320-column tile wide");
+    static_assert(!GN || BN == V5_BN || (W == 128 && ((BN == 256 && BM == 256) || (BN == 128 && BM == 512))),
+                  "the fused GroupNorm only pays where the output is one tile wide: the UNet's N = 320, the VAE's N = 256 / 128 at >= 256-pixel rows");
     static_assert(!(GN && UP), "no caller");
     constexpr int BPIECES = BN / 16, NB_ALL = BPIECES / 8, NB_EXTRA = BPIECES % 8;   // B pieces of a step: NB_ALL per wave + one more for waves < NB_EXTRA
     constexpr int TR = BM / W, HW2 = W + 2, HP = (TR + 2) * HW2;       // tile rows, halo row pitch (pixels), halo pixels
@@ -1798,7 +1799,7 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     constexpr int RING0 = 2 * HBYTES;                                  // byte offset of the B ring
     __shared__ __attribute__((aligned(16))) char smem5[2 * HBYTES + NSTB * BSTAGE];
     static_assert(2 * HBYTES + NSTB * BSTAGE <= 163840, "LDS");
-    static_assert(!GN || 3 + NH <= 9, "fused GroupNorm: my pieces of the next slab are normalised in the read phase of tap 3");
+    static_assert(!GN || NH <= 7, "fused GroupNorm: my (<= 7) pieces of the next slab are normalised in one go in the read phase of tap 3 (28 temporaries)");
     // fused GroupNorm: every wave keeps the 32 scales + 32 shifts of the slab being normalised in 256 bytes of LDS.  Where the
     // halo buffers and the B ring already take all 160 KB (W = 128) the tables live in spare piece slots of halo buffer 0 and the
     // spare (all-zero) pieces of every wave are sent to the last slot instead
@@ -2732,13 +2733,13 @@ static bool v6_plan(const GemmParams& p, V6Plan* out) {
     int bn = 0, bm = V5_BM;
     if (p.N % V5_BN == 0) {
         bn = V5_BN;
-    } else if (p.N % 256 == 0 && wc >= 64 && p.gn_scale == nullptr
+    } else if (p.N % 256 == 0 && wc >= 64 && (p.gn_scale == nullptr || (p.N == 256 && wc == 128 && !up))   // (fused GroupNorm: one tile wide, 128-pixel bands)
 #ifdef LD_AB_BUILD
                && !(g_no_v5 & 64)
 #endif
     ) {
         bn = 256;
-    } else if (p.N % 128 == 0 && wc == 128 && p.gn_scale == nullptr
+    } else if (p.N % 128 == 0 && wc == 128 && (p.gn_scale == nullptr || (p.N == 128 && !up))
 #ifdef LD_AB_BUILD
                && !(g_no_v5 & 256)
 #endif
@@ -2793,8 +2794,16 @@ bool gemm_conv_fuses_groupnorm(const GemmParams& p) {
     // Measured (tools/gnconv_ab.py, same process): fused vs two-pass GroupNorm + the same halo conv: +4 % at N = 320 (level 0, one N
     // tile per M tile), +-0 % at N = 640, -3 % at N = 1280 — every N tile of an M tile normalises the same halo again, so the fusion
     // only pays where the output is one tile wide.
+    // Round 5: also the VAE decoder's one-tile-wide stages — N = 256 at 256-pixel rows, N = 128 at 512-pixel rows (128-pixel bands) — where a
+    // two-pass GroupNorm writes and re-reads 134 - 537 MB per convolution.
     V6Plan pl;
-    return p.N == V5_BN && v6_plan(p, &pl) && pl.bn == V5_BN && !pl.up;
+    if (!v6_plan(p, &pl) || pl.up) return false;
+    if (p.N == V5_BN && pl.bn == V5_BN) return true;
+#ifdef LD_AB_BUILD
+    if (g_no_v5 & 16384) return false;   // A/B: the UNet's N = 320 case only
+#endif
+    // (the 128 -> 3 output convolution — 8 MFMAs per phase — measured a loss with its norm_out fused: VAE decode +0.15 ms, profiles/r05_ab_vae_gn_fused.txt)
+    return pl.wc == 128 && ((p.N == 256 && pl.bn == 256 && pl.bm == V5_BM) || (p.N == 128 && pl.bn == 128 && pl.bm == 512));
 }
 
 int gemm_launch(const GemmParams& pin, hipStream_t stream) {
@@ -2860,8 +2869,17 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
                 p.gn_part = nullptr;
             }
         }
-        if (p.gn_scale != nullptr) {
-            if (p.gn_shift == nullptr || bn6 != V5_BN || pl.up) return LD_ERR_ARG;
+        if (p.gn_scale != nullptr && bn6 != V5_BN) {
+            if (p.gn_shift == nullptr || pl.up || wc != 128 || p.N != bn6 || !((bn6 == 256 && pl.bm == V5_BM) || (bn6 == 128 && pl.bm == 512))) return LD_ERR_ARG;
+            if (bn6 == 256) {
+                t_last_kernel = "conv6_kernel<W128,halo+groupnorm,256>";
+                hipLaunchKernelGGL((conv6_kernel<128, true, 256>), grid, dim3(512), 0, stream, p);
+            } else {
+                t_last_kernel = "conv6_kernel<W128,halo+groupnorm,128x512>";
+                hipLaunchKernelGGL((conv6_kernel<128, true, 128, 512>), grid, dim3(512), 0, stream, p);
+            }
+        } else if (p.gn_scale != nullptr) {
+            if (p.gn_shift == nullptr || pl.up) return LD_ERR_ARG;
             t_last_kernel = wc == 16 ? "conv6_kernel<W16,halo+groupnorm>" : wc == 32 ? "conv6_kernel<W32,halo+groupnorm>"
                           : wc == 64 ? "conv6_kernel<W64,halo+groupnorm>" : "conv6_kernel<W128,halo+groupnorm>";
             switch (wc) {

@@ -202,6 +202,38 @@ struct VRun {
         }
     }
 
+    // GroupNorm (eps 1e-6) + swish + 3x3 convolution (norm1 -> conv1, norm2 -> conv2 of a ResnetBlock): where the convolution's output is one
+    // halo tile wide (N = 256 at 256-pixel rows, N = 128 at 512-pixel rows) the normalisation is applied inside its halo loader and only the
+    // statistics are finalised here (Exec::gn_silu_conv); otherwise the two-pass GroupNorm into `g`, then the convolution, as before.
+    void gn_conv(const half_t* x, int cin, int H, int W, int gslot, int bslot, half_t* g, int wslot, int cbslot, int cout, const half_t* R, half_t* out,
+                 float* stats) {
+        GemmParams p;
+        p.conv = 1;
+        p.ksize = 3;
+        p.pad = -1;
+        p.A = x; p.C1 = cin;
+        p.Hs = p.Hv = p.Ho = H; p.Ws = p.Wv = p.Wo = W; p.stride = 1;
+        p.W = P(wslot); p.ldw = 9 * cin;
+        p.M = n * H * W; p.N = cout; p.K = 9 * cin;
+        p.bias_n = P(cbslot);
+        p.R = R; p.ldr = cout;
+        p.C = out; p.ldc = cout;
+        int done = 0;
+        if (stats != nullptr) {
+            p.gn_part = stats;
+            p.gn_part_done = &done;
+        }
+        const bool ready = x == st_of && st_P > 0;
+        ex.gn_silu_conv(p, n, H * W, P(gslot), P(bslot), 1e-6f, g, ready ? st_buf : nullptr, ready ? st_P : 0);
+        if (stats != nullptr) {
+            st_of = out;
+            st_buf = stats;
+            st_P = done;
+        } else if (out == st_of) {
+            st_of = nullptr;
+        }
+    }
+
     // ResnetBlock.forward, LD.py:3560-3576 (GroupNorm eps 1e-6, swish)
     half_t* resblock(const VResW& r, const half_t* x, int H, int W) {
         Arena& ar = *ex.arena;
@@ -210,19 +242,18 @@ struct VRun {
         float* so = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(n, H * W)));   // statistics of `out` (for the next GroupNorm)
         const size_t mk = ar.mark();
         half_t* g1 = ar.halfs(M * r.cin);
-        gn(x, r.cin, H * W, r.n1_g, r.n1_b, 1, g1);
         half_t* h1 = ar.halfs(M * r.cout);
         float* s1 = reinterpret_cast<float*>(ar.alloc(groupnorm_workspace_bytes(n, H * W)));
-        conv(g1, r.cin, H, W, H, W, 3, r.c1_w, r.c1_b, r.cout, nullptr, h1, 1, -1, 0, 0, s1);
+        gn_conv(x, r.cin, H, W, r.n1_g, r.n1_b, g1, r.c1_w, r.c1_b, r.cout, nullptr, h1, s1);
         half_t* g2 = r.cout <= r.cin ? g1 : ar.halfs(M * r.cout);
-        gn(h1, r.cout, H * W, r.n2_g, r.n2_b, 1, g2);
         const half_t* skip = x;
         if (r.nin_w >= 0) {
-            half_t* sk = h1;   // h1 is dead after norm2
-            conv(x, r.cin, H, W, H, W, 1, r.nin_w, r.nin_b, r.cout, nullptr, sk);
+            // (h1 stays live until conv2 has read it — the fused GroupNorm reads the raw tensor — so the shortcut gets its own buffer)
+            half_t* sk = ar.halfs(M * r.cout);
+            conv(x, r.cin, H, W, H, W, 1, r.nin_w, r.nin_b, r.cout, nullptr, sk);   // (writes no statistics; h1's stay valid)
             skip = sk;
         }
-        conv(g2, r.cout, H, W, H, W, 3, r.c2_w, r.c2_b, r.cout, skip, out, 1, -1, 0, 0, so);
+        gn_conv(h1, r.cout, H, W, r.n2_g, r.n2_b, g2, r.c2_w, r.c2_b, r.cout, skip, out, so);
         ar.release(mk);
         return out;
     }

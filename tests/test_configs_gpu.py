@@ -117,7 +117,7 @@ def test_vae_decode_512_and_1024(hw, sub):
 
 def test_vae_decode_non_square_bands_against_oracle():
     """SD1.5 VAE decoder on a NON-square latent (48 x 32 -> 384 x 256 pixels), batch 2: rows of 32 / 64 pixels (too few halo tiles at this size: implicit-GEMM kernel + split-K), 128 pixels
-    (halo tiles of whole rows), 256 pixels (two 128-pixel column bands per row, 4-row x 128-column tiles for N = 128, the upsampling loader
+    (halo tiles of whole rows), 256 pixels (two 128-pixel column bands per row, 4-row x 128-column tiles for N = 128 with the fused GroupNorm, the upsampling loader
     into a banded image) and the MFMA output convolution with exactly 192 tiles per image pair — against the oracle on the host."""
     from lightdiffusion_amd.unet import synthetic_vae
     from oracle import sd15_ref as O
@@ -127,7 +127,9 @@ def test_vae_decode_non_square_bands_against_oracle():
     img = v.decode(z)
     assert img.shape == (2, 384, 256, 3)
     kinds = {r[4] for r in v.profile_decode(z)}
-    assert {"conv6_kernel<W128,halo,128x512>", "conv6_kernel<W128,halo,256,up>", "conv6_kernel<W128,halo,256>", "conv6_kernel<W128,halo,32x512>"} <= kinds, kinds
+    # (round 5: the one-tile-wide stages — N = 256 at 256-pixel rows, N = 128 at 4-row x 128-column tiles — apply their GroupNorm inside the halo loader)
+    assert {"conv6_kernel<W128,halo+groupnorm,128x512>", "conv6_kernel<W128,halo,256,up>", "conv6_kernel<W128,halo+groupnorm,256>",
+            "conv6_kernel<W128,halo,32x512>"} <= kinds, kinds
     ref = O.vae_decode(W.synth_state_dict(W.vae_decoder_param_shapes(cfg)), cfg, z[:1])
     assert float((img[:1] - ref).abs().max()) < 2.0 / 255.0
     img1 = v.decode(z[1:])                                     # batch 1: other tile counts (the output conv falls back below 192 tiles)

@@ -415,6 +415,11 @@ def test_linear_ln_batch1_shapes(ops, M, C, N):
     (4, 128, 128, 320, 0, 320, False, False),    # fused, W = 128 (tables live inside the halo buffer)
     (64, 32, 32, 640, 0, 320, True, True),       # fused, W = 32
     (16, 32, 32, 640, 0, 640, True, True),       # two N tiles: two-pass GroupNorm + the plain halo kernel (split over K)
+    (2, 256, 256, 256, 0, 256, False, True),     # fused (round 5), the VAE's 256-pixel-row stage: 128-pixel bands, one 256-column tile
+    (1, 256, 256, 512, 0, 256, False, False),    # ... its 512 -> 256 convolution
+    (1, 256, 384, 128, 0, 128, False, True),     # fused, the VAE's last stage: 512 x 128 tiles (four rows of a band), non-square image
+    (1, 512, 256, 256, 0, 128, True, False),     # ... its 256 -> 128 convolution (a row vector is not a VAE case: covered anyway)
+    (2, 256, 256, 256, 0, 512, False, False),    # two 256-column tiles: stays two-pass
     (2, 12, 10, 64, 64, 128, True, True)])       # not eligible: two-pass GroupNorm + plain conv through the same entry point
 def test_groupnorm_silu_conv(ops, n, h, w, c1, c2, cout, rv, res):
     x1 = r16((n, c1, h, w), 101, 2.0) + 0.5
