@@ -317,6 +317,47 @@ def main():
             f"dominant {roof['kernel']} {roof['achieved']:.0f} {roof['unit']} ({roof['bound']} roof, {100 * roof['frac']:.1f} %)")
         return res
 
+    def run_hook_route(B, L, K, Wm, cfg_scale, product_ms):
+        """The reference's OWN seam, timed: what `calc_cond_batch` + `cfg_function` do per step around `model_function_wrapper`
+        (LD.py:2515-2606) — cat([x, x]), cat([sigma, sigma]), a freshly concatenated [uncond, cond] context, the wrapper call with
+        cond_or_uncond == [1, 0], chunk, uncond + (cond - uncond) * cfg, an Euler update — with `MI355XUNet.__call__` on the seam (graph
+        replay + device-side guards, unet.py).  The dictionary has the keys and order of the arguments recorded from the reference in
+        tests/golden/samplers.npz (hook_input / hook_timestep / hook_ctx / hook_cond_or_uncond), at this workload's size."""
+        gen = torch.Generator().manual_seed(4321 + rank)
+        x = (torch.randn(B, 4, L, L, generator=gen) * 10.0).to(dev)
+        unc = cond2[0:1].expand(B, -1, -1).contiguous()
+        cnd = cond2[1:2].expand(B, -1, -1).contiguous()
+        sig = sampling.KSampler1(model, steps=30, device=dev, sampler="euler_ancestral", scheduler="normal", denoise=None,
+                                 model_options=model.model_options).sigmas.to(dev)
+        ones = torch.ones(B, device=dev)
+        state = {"x": x}
+
+        def steps(n):
+            xx = state["x"]
+            for i in range(n):
+                j = i % (len(sig) - 1)
+                s = sig[j] * ones
+                cou = [1, 0]
+                c = {"c_crossattn": torch.cat([unc, cnd]), "transformer_options": {"cond_or_uncond": cou[:], "sigmas": s}}
+                out = unet(None, {"input": torch.cat([xx, xx]), "timestep": torch.cat([s, s]), "c": c, "cond_or_uncond": cou})
+                u, cn = out.chunk(2)
+                den = u + (cn - u) * cfg_scale
+                xx = xx + (xx - den) / sig[j] * (sig[j + 1] - sig[j])
+            state["x"] = xx
+
+        steps(max(Wm, 3))
+        barrier()
+        t0 = time.perf_counter()
+        steps(K)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        run = unet._hook.get((2 * B, L, L))
+        return {"what": "MI355XUNet.__call__ on model_function_wrapper (LD.py:2558-2567) driven as calc_cond_batch + cfg_function drive it: "
+                        "fresh cat([x, x]) / cat([uncond, cond]) per step, torch CFG mix + Euler update",
+                "batch": B, "steps": K, "steps_per_s": K / el, "ms_per_step": 1e3 * el / K,
+                "route": "pair graph" if run is not None and run.pair is not None and run.pair.graph is not None and not run.halves_differed else "plain graph",
+                "product_loop_ms_per_step": product_ms, "vs_product_loop": (1e3 * el / K) / product_ms if product_ms else None}
+
     K, Wm = args.steps, args.warmup
     out_extra = {}
     head = None
@@ -331,6 +372,11 @@ def main():
         head = out_extra.get("batch1") or out_extra.get("hires")
 
     if args.only is None and not args.no_extras and world == 1:
+        out_extra["hook_route"] = {"batch8": run_hook_route(args.batch, 64, K, Wm, args.cfg, head["ms_per_step"]),
+                                   "batch1": run_hook_route(1, 64, K, min(Wm, 20), args.cfg, out_extra["batch1"]["ms_per_step"])}
+        log(f"hook route: B={args.batch} {out_extra['hook_route']['batch8']['ms_per_step']:.3f} ms/step "
+            f"({out_extra['hook_route']['batch8']['vs_product_loop']:.3f}x the product loop), "
+            f"B=1 {out_extra['hook_route']['batch1']['ms_per_step']:.3f} ms/step ({out_extra['hook_route']['batch1']['vs_product_loop']:.3f}x)")
         vae = synthetic_vae(W.sd15_vae_config(), max_batch=args.batch, max_hw=(64, 64), device=dev)
         lat = torch.randn(args.batch, 4, 64, 64, generator=torch.Generator().manual_seed(5)) * 4.0
 

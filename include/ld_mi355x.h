@@ -176,6 +176,13 @@ int ld_op_timestep_embed(const float* sigma, const float* log_sigmas, int n_sigm
 /* guidance / sampler elementwise on fp32 latents: out = u + (c-u)*cfg with den2 = [u ; c];  x = a*x + b*y + c*z */
 int ld_op_cfg_combine(const float* den2, float* out, float cfg, size_t n_half, void* stream);
 int ld_op_axpby(float* x, float a, const float* y, float b, const float* z, float c, size_t n, void* stream);
+/* Device-side guards of the model_function_wrapper hook (LD.py:2558-2567; the object on that seam replays a captured hipGraph the way the
+ * reference's stable-fast patch does with enable_cuda_graph, LD.py:9896-9933): flags[0] = epoch when the 32-bit words of a and b differ
+ * (the step's c_crossattn against the conditioning the resident cross-attention K / V^T were projected from), flags[1] = epoch when the two
+ * halves of x (2 * half_words_x words) or of sigma (2 * half_sigma floats, half_sigma <= 256) differ (calc_cond_batch's cat([x_in, x_in]),
+ * LD.py:2515-2547).  flags: two ints the device can write (device or pinned host memory); never reset — the host compares with its epoch. */
+int ld_op_hook_check(const void* a, const void* b, size_t words_ab, const void* x, size_t half_words_x, const void* sigma, int half_sigma,
+                     int* flags, int epoch, void* stream);
 
 /* The LayerNorm fold of the UNet's transformer blocks (BasicTransformerBlock, LD.py:4117-4162: every attention / GEGLU
  * projection reads LayerNorm(x)) as an operator pair, for parity tests: t[M][C] = x · w_prod^T + b_prod (the GEMM that writes the

@@ -89,6 +89,7 @@ SIGNATURES = {
     "ld_op_timestep_embed": (_I, [_P, _P, _I, _I, _I, _P, _P, _P]),
     "ld_op_cfg_combine": (_I, [_P, _P, _F, _Z, _P]),
     "ld_op_axpby": (_I, [_P, _F, _P, _F, _P, _F, _Z, _P]),
+    "ld_op_hook_check": (_I, [_P, _P, _Z, _P, _Z, _P, _I, _P, _I, _P]),
     "ld_op_linear_ln": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _Z, _P]),
     "ld_op_linear_ln_geglu": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _Z, _P]),
     "ld_op_bislerp": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

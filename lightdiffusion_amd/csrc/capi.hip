@@ -267,6 +267,11 @@ int ld_op_cfg_combine(const float* den2, float* out, float cfg, size_t n_half, v
     return cfg_combine_launch(den2, out, cfg, n_half, (hipStream_t)stream);
 }
 
+int ld_op_hook_check(const void* a, const void* b, size_t words_ab, const void* x, size_t half_words_x, const void* sigma, int half_sigma,
+                     int* flags, int epoch, void* stream) {
+    return hook_check_launch(a, b, words_ab, x, half_words_x, sigma, half_sigma, flags, epoch, (hipStream_t)stream);
+}
+
 int ld_op_axpby(float* x, float a, const float* y, float b, const float* z, float c, size_t n, void* stream) {
     return axpby_launch(x, a, y, b, z, c, n, (hipStream_t)stream);
 }

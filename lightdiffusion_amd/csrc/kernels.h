@@ -113,5 +113,8 @@ int fill_half_launch(half_t* dst, size_t n, float v, hipStream_t stream);
 // sampler / guidance elementwise (fp32 latents)
 int cfg_combine_launch(const float* den2, float* out, float cfg, size_t n_half, hipStream_t stream);   // out = u + (c-u)*cfg, den2=[u;c]
 int axpby_launch(float* x, float a, const float* y, float b, const float* z, float c, size_t n, hipStream_t stream);  // x = a*x + b*y + c*z
+// wrapper-hook guards: flags[0] = epoch when a != b (words_ab 32-bit words), flags[1] = epoch when the halves of x / sigma differ
+int hook_check_launch(const void* a, const void* b, size_t words_ab, const void* x, size_t half_words_x, const void* sigma, int half_sigma,
+                      int* flags, int epoch, hipStream_t stream);
 // bislerp (LD.py:429-518): fp32 NCHW [n][c][h][w] -> [n][c][h_new][w_new]; tmp holds n*c*h*w_new floats (width pass first)
 int bislerp_launch(const float* x, float* tmp, float* y, int n, int c, int h, int w, int h_new, int w_new, hipStream_t stream);

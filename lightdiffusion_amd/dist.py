@@ -47,9 +47,9 @@ def broadcast_conditioning(tensors: Sequence[Optional[torch.Tensor]], shapes: Se
                            device=None) -> List[torch.Tensor]:
     """One collective: pack [cond, uncond, ...] (fp32) into a flat buffer on `src`, broadcast, unpack everywhere.
     Non-source ranks pass None tensors and the agreed `shapes` (token count is fixed by the prompt chunking: 77·k)."""
-    if world_size() == 1:
+    if not dist.is_initialized():
         return [t for t in tensors]
-    rank = dist.get_rank()
+    rank = dist.get_rank()                       # (a world-1 group still runs the collective: the single-GPU RCCL check relies on it)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     sizes = [int(torch.Size(s).numel()) for s in shapes]
@@ -72,7 +72,7 @@ def full_batch_noise(shape_global: Sequence[int], seed: int, rows: slice) -> tor
 
 def gather_images(images: torch.Tensor, dst: int = 0) -> Optional[torch.Tensor]:
     """Collect the per-rank [b, H, W, 3] images (any dtype) on `dst` in rank order; other ranks get None."""
-    if world_size() == 1:
+    if not dist.is_initialized():
         return images
     rank, world = dist.get_rank(), dist.get_world_size()
     counts = [torch.zeros(1, dtype=torch.long, device=images.device) for _ in range(world)]

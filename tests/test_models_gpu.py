@@ -117,6 +117,51 @@ def test_wrapper_hook_contract(tiny_unet):
     assert torch.equal(out2, out)
 
 
+def test_wrapper_hook_replays_graphs_bitwise_and_follows_the_prompt(tiny_unet):
+    """the object on the reference's `model_function_wrapper` seam replays captured hipGraphs (the counterpart of
+    StableFastPatch's enable_cuda_graph, LD.py:9896-9933).  [uncond, cond] batches of ONE latent take the CFG-pair graph, checked on the
+    device; graph == eager bitwise on both routes; a second prompt of the same shape (recycled address or not) is not stale; halves that
+    differ fall back to the plain graph within the same call."""
+    g = load_golden("samplers")
+    x, s, ctx = g["hook_input"].to(DEV), g["hook_timestep"].to(DEV), g["hook_ctx"].to(DEV)
+    b = x.shape[0] // 2
+    assert torch.equal(x[:b], x[b:]) and torch.equal(s[:b], s[b:])          # what calc_cond_batch recorded: cat([x_in, x_in])
+    mk = lambda xx, cc: {"input": xx, "timestep": s, "c": {"c_crossattn": cc, "transformer_options": {"cond_or_uncond": [1, 0], "sigmas": s[:b]}},
+                         "cond_or_uncond": [1, 0]}
+    key = (x.shape[0], x.shape[2], x.shape[3])
+    tiny_unet._hook.clear()
+    out = tiny_unet(None, mk(x, ctx.clone()))
+    run = tiny_unet._hook[key]
+    assert run.pair.graph is not None and run.plain.graph is None and not run.halves_differed
+    eager_pair = tiny_unet.forward_pair(x[:b].contiguous(), s[:b].contiguous())
+    assert torch.equal(out, eager_pair)                                       # graph == eager, bit for bit
+    cfg = W.tiny_unet_config()
+    sd = W.synth_state_dict(W.unet_param_shapes(cfg))
+    ms = O.ModelSampling()
+    assert rel_l2(out.cpu(), O.apply_model(sd, cfg, ms, x.cpu(), s.cpu(), ctx.cpu())) < UNET_TOL
+    # a second prompt of the same shape: the speculative replay is redone after the device-side check found the conditioning changed
+    ctx2 = ctx + 0.5 * torch.randn(ctx.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+    out_b = tiny_unet(None, mk(x, ctx2))
+    assert rel_l2(out_b.cpu(), O.apply_model(sd, cfg, ms, x.cpu(), s.cpu(), ctx2.cpu())) < UNET_TOL
+    assert not torch.equal(out_b, out)
+    assert torch.equal(tiny_unet(None, mk(x, ctx2.clone())), out_b)           # same prompt again: cached projections, same bits
+    assert torch.equal(tiny_unet(None, mk(x, ctx.clone())), out)              # and back to the first prompt
+    # halves that are NOT the same latents: the call itself falls back to the plain graph, == the eager plain forward bit for bit
+    x2 = x.clone()
+    x2[b:] += 0.25
+    out2 = tiny_unet(None, mk(x2, ctx.clone()))
+    assert run.halves_differed and run.plain.graph is not None
+    assert torch.equal(out2, tiny_unet.forward(x2, s))
+    assert rel_l2(out2.cpu(), O.apply_model(sd, cfg, ms, x2.cpu(), s.cpu(), ctx.cpu())) < UNET_TOL
+    # eager switch (A/B) and unload: .to("cpu") drops the captured graphs like the reference's graph-mode plugin does (LD.py:9921-9933)
+    tiny_unet.hook_graph = False
+    try:
+        assert torch.equal(tiny_unet(None, mk(x2, ctx.clone())), out2)
+    finally:
+        tiny_unet.hook_graph = True
+    assert tiny_unet.to(torch.device("cpu")) is tiny_unet and not tiny_unet._hook and not tiny_unet._denoisers
+
+
 def test_sd15_unet_golden():
     from lightdiffusion_amd.unet import synthetic_unet
     g = load_golden("unet_sd15_64x64")

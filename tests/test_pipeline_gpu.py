@@ -169,3 +169,16 @@ def test_multiple_conds_per_list_match_reference(stack):
     assert rel_l2(out, g["out"]) < TRAJ_TOL
     out2 = nodes.KSampler2().sample(model, 4321, 5, 6.0, "euler_ancestral", "normal", pos, neg, lat)[0]["samples"]   # wrapper = the UNet itself
     assert torch.equal(out, out2)
+
+
+def test_rccl_group_and_graph_capture_in_one_process():
+    """the "nccl" (= RCCL) backend at world = 1 on cuda:0, `dist.broadcast_conditioning`, then `KSampler2.sample`
+    (captures + replays the step's hipGraph with the process group's watchdog thread alive: capture_error_mode="thread_local"), the
+    wrapper hook's own graphs, then `dist.gather_images`; latents bitwise equal to the run without a process group.  A child process
+    (tools/rccl_graph_check.py) so that a hung communicator cannot take the suite with it.  All a one-GPU box can show of config #4."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join("tools", "rccl_graph_check.py")], cwd=root, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "rccl world-1 + hipGraph ok" in r.stdout
