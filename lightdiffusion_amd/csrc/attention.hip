@@ -20,7 +20,8 @@
 //  * a d that is an odd multiple of 8 leaves one pad chunk in the last QK^T k-step; the matching Q fragment is zero and
 //    the pad chunk reads the next row's first chunk (or the zero-filled slack after the last row): 0 * finite = 0.
 //  * lazy softmax reference: O / l are rescaled only when a tile maximum exceeds the running reference by > 8.
-// Head dims: d % 8 == 0, d <= 160 (SD1.5: 40 / 80 / 160).  Template DK = ceil(d/16) k-steps of QK^T.
+// Head dims: d % 8 == 0, d <= 160 (SD1.5: 40 / 80 / 160); one head of d = 512 with row-major V: flash_attn512_kernel below (the VAE).
+// Template DK = ceil(d/16) k-steps of QK^T.
 #include <cstdlib>
 #include <type_traits>
 
@@ -356,6 +357,196 @@ __global__ __launch_bounds__(64 * NW, WPS) void flash_attn2_kernel(const AttnPar
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// flash_attn512_kernel (round 6): ONE head of 512 channels, row-major V — the VAE's AttnBlock (LD.py:3591-3642), which until now ran as
+// three GEMMs around a row softmax over a materialised L x L score matrix (2.1 GB of fp16 at 1024^2, b = 4).
+//  * d = 512 turns the attention unit around: per 32 x 32 score block 32 QK^T + 32 PV MFMAs against 16 exponentials per lane (d = 40: 7
+//    MFMAs) — matrix-bound; what the kernel has to manage is REGISTERS: O^T of 32 queries is 16 tiles = 256 accumulator registers and the
+//    Q^T fragments of 32 queries are another 128.  (One wave per SIMD with the whole 512-entry file was tried first: hipcc keeps the 256
+//    accumulators in AGPRs and spills the 128 Q registers to scratch, one reload per MFMA, whatever is pinned.)
+//  * so the 512 channels are split over a PAIR of waves: wave (qb, ch) of a 128-query workgroup (8 waves, two per SIMD) owns queries
+//    32 qb .. 32 qb + 31 and channels 256 ch .. 256 ch + 255: half of Q^T (64 VGPRs), half of O^T (128 accumulators).  Per 32-key tile it
+//    takes its half of the d-reduction of S^T (16 MFMAs), the pair swaps the fp32 partials through LDS (4 KB each way), both add them in the
+//    same order (a + b == b + a: the two waves hold bitwise the same scores, reference and probabilities), run the softmax of the 32 x 32
+//    block (16 exponentials: cheap against 32 MFMAs) and their half of O^T += V^T P^T (16 MFMAs).
+//  * 32-key tiles: K tile 32 KB + V tile 32 KB, double-buffered by LDS-DMA one tile ahead = 128 KB, + 32 KB of exchange = all 160 KB.
+//  * K rows permuted (bits 2 <-> 3) and chunk-swizzled (c ^ (row & 7)) as in flash_attn2_kernel; V rows of 64 chunks with their 64-byte
+//    groups XORed with (row & 3) for the transposing reads (the VROW path's rule).
+//  * S^T starts at 0 (inline constant C operand); the softmax reference is subtracted on the vector side.
+//  * D = 256 (a narrower VAE, e.g. the tests' tiny configuration) is the same kernel with half the k-steps and accumulator tiles.
+template <int D, bool MASKED>
+__global__ __launch_bounds__(512, 2) void flash_attn512_kernel(const AttnParams p) {
+    constexpr int DCH = D / 8, KT = 32;
+    constexpr int NKS = D / 32, NT = D / 64;             // QK^T k-steps and O^T tiles of ONE wave (half the channels)
+    constexpr int LIT = KT * DCH / 512;                  // loader wave-instructions per tile and operand
+    constexpr int TILE_H = KT * D;                       // halfs per K tile and per V tile
+    __shared__ __attribute__((aligned(16))) half_t smem[4 * TILE_H + 8 * 2048];   // [buf][K tile | V tile], then 8 x 4 KB of exchange
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qbw = wid & 3, ch = wid >> 2;
+    const int r = lane & 31, hh = lane >> 5;
+    const int qblocks = (p.Lq + 127) / 128;
+    int bid = xcd_remap(blockIdx.x, qblocks * p.B);
+    const int qb = bid % qblocks, b = bid / qblocks;
+    const half_t* Qg = p.Q + (long long)b * p.sQ;
+    const half_t* Kg = p.K + (long long)b * p.sK;
+    const half_t* Vg = p.V + (long long)b * p.sV;
+    const half_t* zp = reinterpret_cast<const half_t*>(g_att_zero);
+    const int qrow = qb * 128 + qbw * 32 + r;
+    const float c2 = p.scale * 1.44269504088896340736f;
+    half8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        float qv[8];
+        unpack8(qrow < p.Lq ? ld16(Qg + (long long)qrow * p.ldq + (D / 2) * ch + 16 * ks + 8 * hh) : zero16(), qv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] *= c2;
+        qf[ks] = as_half8(pack8(qv));
+    }
+    // loader: wave-instruction i of a tile covers the 16-byte slots i * 512 + tid: LDS row (i * 512 + tid) / DCH, physical chunk % DCH.
+    // K: that row holds key perm(row) (bits 2 <-> 3) and the slot's source chunk is chunk ^ (row & 7); V: row = key, chunk ^ ((row & 3) << 2).
+    int lkey[LIT], lkoff[LIT], lvoff[LIT];
+#pragma unroll
+    for (int i = 0; i < LIT; ++i) {
+        const int q = i * 512 + tid, row = q / DCH, c = q % DCH;
+        lkey[i] = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);
+        lkoff[i] = (c ^ (row & 7)) << 3;
+        lvoff[i] = (c ^ ((row & 3) << 2)) << 3;
+    }
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    auto issue = [&](int key0, int buf) {
+        const unsigned Kb = smem_base + (unsigned)(buf * 2 * TILE_H) * 2u + (unsigned)(wid * 64) * 16u;
+        const unsigned Vb = Kb + (unsigned)TILE_H * 2u;
+#pragma unroll
+        for (int i = 0; i < LIT; ++i) {
+            const int key = key0 + lkey[i];
+            const half_t* src = Kg + (long long)key * p.ldk + lkoff[i];
+            glds16((MASKED && key >= p.Lk) ? zp : src, Kb + (unsigned)(i * 512) * 16u);
+        }
+#pragma unroll
+        for (int i = 0; i < LIT; ++i) {
+            const int key = key0 + (i * 512 + tid) / DCH;
+            const half_t* src = Vg + (long long)key * p.ldv + lvoff[i];
+            glds16((MASKED && key >= p.Lk) ? zp : src, Vb + (unsigned)(i * 512) * 16u);
+        }
+    };
+    // fragment offsets (halfs).  K: row r, chunk ((2 (ks & 3) + hh) ^ (r & 7)) + 8 (ks >> 2) + (DCH / 2) ch.
+    int koff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) koff[j] = (r * DCH + ((2 * j + hh) ^ (r & 7)) + (DCH / 2) * ch) << 3;
+    // V (see flash_attn2_kernel's VROW comment): lane (r, hh) = 16-lane group (r >> 4) + 2 hh; lane 4 tq + tp addresses row tq, channels 4 tp ..
+    int voff[4];
+    {
+        const int tq = (r >> 2) & 3, tp = r & 3, g1 = (r >> 4) & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            voff[j] = TILE_H + (8 * hh + tq) * D + (D / 2) * ch + ((j ^ tq) << 5) + ((2 * g1 + (tp >> 1)) << 3) + 4 * (tp & 1);
+    }
+    float* xmine = reinterpret_cast<float*>(smem + 4 * TILE_H) + wid * 1024 + lane * 4;
+    const float* xpeer = reinterpret_cast<const float*>(smem + 4 * TILE_H) + (wid ^ 4) * 1024 + lane * 4;
+    f32x16 o[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.f;
+    constexpr float TAU = 8.0f;
+    float m_ref = 0.f, l_run = 0.f;
+    const int ntiles = (p.Lk + KT - 1) / KT;
+    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): retire the Q loads here (see flash_attn2_kernel)
+    issue(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * KT;
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();      // tile t has landed for everyone; tile t-1's buffers and exchange slots are free
+        if (t + 1 < ntiles) issue(key0 + KT, (t + 1) & 1);
+        const half_t* T = smem + (t & 1) * 2 * TILE_H;
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const half8 kf = as_half8(ld16(T + koff[ks & 3] + 64 * (ks >> 2)));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(xmine + g * 256) = (f32x4){s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // the pair's partial scores are in LDS
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xpeer + g * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[4 * g + e] += x[e];
+        }
+        if (MASKED) {
+            if (p.causal || key0 + KT > p.Lk) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    const int key = key0 + ((i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1));
+                    if (key >= p.Lk || (p.causal && key > qrow)) s[e] = -INFINITY;
+                }
+            }
+        }
+        float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+        for (int e = 3; e + 1 < 16; e += 2) mx = fmaxf(fmaxf(mx, s[e]), s[e + 1]);
+        mx = fmaxf(mx, s[15]);
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float over = mx - m_ref;
+        if (t == 0 || __any(over > TAU)) {
+            const float delta = t == 0 ? (mx == -INFINITY ? 0.f : over) : (over > TAU ? over : 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            m_ref += delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[tt][e] *= alpha;
+        }
+        float psum = 0.f;
+        half8 pf[2];
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(s[e] - m_ref);
+            const float p1 = __builtin_amdgcn_exp2f(s[e + 1] - m_ref);
+            psum += p0 + p1;
+            const half2v h2 = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+            pf[e >> 3][e & 7] = h2[0];
+            pf[e >> 3][(e & 7) + 1] = h2[1];
+        }
+        l_run += psum;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const half_t* vsrc = T + voff[tt & 3] + 128 * (tt >> 2) + 16 * k2 * D;
+                const half4v lo = __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vsrc)));
+                const half4v hi = __builtin_bit_cast(half4v, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(vsrc + 4 * D)));
+                const half8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[k2], o[tt], 0, 0, 0);
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < p.Lq) {
+        half_t* Og = p.O + (long long)b * p.sO + (long long)qrow * p.ldo + (D / 2) * ch;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[tt][4 * g + e] * inv);
+                *reinterpret_cast<half4*>(Og + tt * 32 + 8 * g + 4 * hh) = h;
+            }
+    }
+}
+
+
 thread_local const char* t_last_attn_kernel = "";
 
 template <int DK, bool VROW>
@@ -383,6 +574,16 @@ void launch_attn(const AttnParams& p, hipStream_t s) {
     }
 }
 
+template <int D>
+void launch_attn512(const AttnParams& p, hipStream_t s) {
+    const int nblk = ((p.Lq + 127) / 128) * p.B;
+    const bool masked = p.causal || (p.Lk % 32) != 0;
+    static const std::string names[2] = {"flash_attn512_kernel<" + std::to_string(D) + ",plain>", "flash_attn512_kernel<" + std::to_string(D) + ",masked>"};
+    t_last_attn_kernel = names[masked ? 1 : 0].c_str();
+    if (masked) hipLaunchKernelGGL((flash_attn512_kernel<D, true>), dim3(nblk), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((flash_attn512_kernel<D, false>), dim3(nblk), dim3(512), 0, s, p);
+}
+
 }  // namespace
 
 const char* attention_last_kernel_name() { return t_last_attn_kernel; }
@@ -390,7 +591,8 @@ const char* attention_last_kernel_name() { return t_last_attn_kernel; }
 int attention_launch(const AttnParams& p, hipStream_t stream) {
     if (p.Q == nullptr || p.K == nullptr || (p.Vt == nullptr) == (p.V == nullptr) || p.O == nullptr) return LD_ERR_ARG;   // exactly one of V^T / V
     if (p.B <= 0 || p.H <= 0 || p.Lq <= 0 || p.Lk <= 0) return LD_ERR_SHAPE;
-    if (p.d % 8 || p.d <= 0 || p.d > 160) return LD_ERR_SHAPE;
+    // d = 512 / 256: the VAE's single head, row-major V only (flash_attn512_kernel)
+    if (p.d % 8 || p.d <= 0 || (p.d > 160 && !((p.d == 512 || p.d == 256) && p.H == 1 && p.V != nullptr))) return LD_ERR_SHAPE;
     // 16-byte row copies: every row start must be 16-byte aligned; V^T rows are read in 8-key chunks, so the
     // V^T buffer must be allocated (and zero-padded) to a multiple of 8 keys per row
     if ((p.ldq & 7) || (p.ldk & 7) || (p.ldo & 3) || (p.sQ & 7) || (p.sK & 7) || (p.sV & 7)) return LD_ERR_SHAPE;
@@ -403,6 +605,11 @@ int attention_launch(const AttnParams& p, hipStream_t stream) {
     if (p.V != nullptr) {   // row-major V (the UNet's fused q|k|v projection)
         if ((p.ldv & 7) || p.ldv < hd) return LD_ERR_SHAPE;
         if (p.B > 1 && p.sV < (long long)(p.Lk - 1) * p.ldv + hd) return LD_ERR_SHAPE;
+        if (p.d == 512 || p.d == 256) {
+            if (p.d == 512) launch_attn512<512>(p, stream);
+            else launch_attn512<256>(p, stream);
+            return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
+        }
         switch (dk) {
             case 1: launch_attn<1, true>(p, stream); break;
             case 2: launch_attn<2, true>(p, stream); break;

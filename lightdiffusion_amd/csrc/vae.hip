@@ -1,8 +1,8 @@
 // KL-VAE decoder executor: post_quant_conv + Decoder.forward (LD.py:3470-3473, 3857-3882) + VAE.decode's clamp and
 // NHWC output (LD.py:6357-6381), on NHWC fp16 activations with the same kernels as the UNet.
-// The single-head d=512 mid-block attention (AttnBlock, LD.py:3605-3642) is too wide for the flash kernel's
-// register tile, so it runs as three MFMA GEMMs around a row softmax: S = alpha·Q·K^T, P = softmax(S), O = P·V
-// with V^T produced directly by a swapped projection GEMM.
+// The single-head mid-block attention (AttnBlock, LD.py:3605-3642) runs as one fused [q | k | v] projection + flash_attn512_kernel
+// (attention.hip: the 512 — or 256 — channels split over a pair of waves) since round 6; other widths keep the three MFMA GEMMs around a
+// row softmax (S = alpha·Q·K^T, P = softmax(S), O = P·V with V^T produced directly by a swapped projection GEMM).
 #include <cstring>
 
 #include "runtime.h"
@@ -77,11 +77,11 @@ VAttnW add_vattn(ld_vae* v, const std::string& p, int c) {
     a.n_g = t.add(p + ".norm.weight", PK_VEC, {c});
     a.n_b = t.add(p + ".norm.bias", PK_VEC, {c});
     a.q_w = t.add(p + ".q.weight", PK_MAT, {c, c, 1, 1});
-    a.k_w = t.add(p + ".k.weight", PK_MAT, {c, c, 1, 1}, 16);   // [q;k] as one [2C][C] projection
+    a.k_w = t.add(p + ".k.weight", PK_MAT, {c, c, 1, 1}, 16);   // [q;k;v] as one [3C][C] projection
+    a.v_w = t.add(p + ".v.weight", PK_MAT, {c, c, 1, 1}, 16);
     a.q_b = t.add(p + ".q.bias", PK_VEC, {c});
     a.k_b = t.add(p + ".k.bias", PK_VEC, {c}, 16);
-    a.v_w = t.add(p + ".v.weight", PK_MAT, {c, c, 1, 1});
-    a.v_b = t.add(p + ".v.bias", PK_VEC, {c});
+    a.v_b = t.add(p + ".v.bias", PK_VEC, {c}, 16);
     a.o_w = t.add(p + ".proj_out.weight", PK_MAT, {c, c, 1, 1});
     a.o_b = t.add(p + ".proj_out.bias", PK_VEC, {c});
     return a;
@@ -258,7 +258,7 @@ struct VRun {
         return out;
     }
 
-    // AttnBlock.forward, LD.py:3630-3642
+    // AttnBlock.forward, LD.py:3630-3642 (one head of C channels, pytorch_attention LD.py:3591-3602)
     half_t* attn(const VAttnW& aw, const half_t* x, int H, int W) {
         Arena& ar = *ex.arena;
         const int C = aw.c, L = H * W;
@@ -267,49 +267,71 @@ struct VRun {
         const size_t mk = ar.mark();
         half_t* g = ar.halfs(M * C);
         ex.groupnorm(x, C, nullptr, 0, n, L, P(aw.n_g), P(aw.n_b), 1e-6f, 0, g);
-        half_t* qk = ar.halfs(M * 2 * C);
-        {
-            GemmParams p;
-            p.A = g; p.lda = C; p.W = P(aw.q_w); p.ldw = C;
-            p.M = (int)M; p.N = 2 * C; p.K = C; p.bias_n = P(aw.q_b);
-            p.C = qk; p.ldc = 2 * C;
-            ex.gemm(p);
-        }
-        // key axis padded to a multiple of 8 (16-byte rows): pad keys get zero scores, zero probabilities and a finite V^T
-        // column (bias only), so any latent size works (63x63, 65x65 ...), as in the reference
-        const int Lp = (L + 7) & ~7;
-        half_t* vt = ar.halfs((size_t)n * C * Lp);
-        {   // V^T[b] = Wv · g_b^T + bv (bias along rows)
-            GemmParams p;
-            p.A = P(aw.v_w); p.lda = C; p.sA = 0;
-            p.W = g; p.ldw = C; p.sW = (long long)L * C;
-            p.M = C; p.N = Lp; p.n_valid = L; p.K = C; p.batch = n;
-            p.bias_m = P(aw.v_b);
-            p.C = vt; p.ldc = Lp; p.sC = (long long)C * Lp;
-            ex.gemm(p);
-        }
-        half_t* s = ar.halfs((size_t)n * L * Lp);
-        {   // S_b = Q_b K_b^T / sqrt(C)
-            GemmParams p;
-            p.A = qk; p.lda = 2 * C; p.sA = (long long)L * 2 * C;
-            p.W = qk + C; p.ldw = 2 * C; p.sW = (long long)L * 2 * C;
-            p.M = L; p.N = Lp; p.n_valid = L; p.K = C; p.batch = n;
-            p.alpha = 1.0f / sqrtf((float)C);
-            p.C = s; p.ldc = Lp; p.sC = (long long)L * Lp;
-            ex.gemm(p);
-        }
-        ex.launches += 1;
-        ex.t_begin(KC_MISC, 0.0, 1, "softmax", (long long)n * L, Lp, 0, 1);
-        if (!ex.dry && ex.status == LD_OK) ex.note(softmax_rows_launch(s, n * L, Lp, Lp, ex.stream, L));
-        ex.t_end("softmax_rows_kernel");
-        half_t* o = g;   // reuse
-        {   // O_b = P_b V_b  (W operand = V^T [C][Lp]; the pad keys carry zero probability)
-            GemmParams p;
-            p.A = s; p.lda = Lp; p.sA = (long long)L * Lp;
-            p.W = vt; p.ldw = Lp; p.sW = (long long)C * Lp;
-            p.M = L; p.N = C; p.K = Lp; p.batch = n;
-            p.C = o; p.ldc = C; p.sC = (long long)L * C;
-            ex.gemm(p);
+        half_t* o = g;   // the attention output reuses the normalised tensor's buffer
+        if (C == 512 || C == 256) {
+            // round 6: [q | k | v] as ONE projection, then flash attention over the single head (flash_attn512_kernel: V row-major, the
+            // score matrix never exists — it was 2.1 GB of fp16 at 1024^2, b = 4 — and the V^T GEMM, the softmax pass and a GEMM are gone)
+            half_t* qkv = ar.halfs(M * 3 * C);
+            {
+                GemmParams p;
+                p.A = g; p.lda = C; p.W = P(aw.q_w); p.ldw = C;
+                p.M = (int)M; p.N = 3 * C; p.K = C; p.bias_n = P(aw.q_b);
+                p.C = qkv; p.ldc = 3 * C;
+                ex.gemm(p);
+            }
+            AttnParams a;
+            a.Q = qkv; a.K = qkv + C; a.V = qkv + 2 * C;
+            a.ldq = a.ldk = a.ldv = 3 * C;
+            a.sQ = a.sK = a.sV = (long long)L * 3 * C;
+            a.O = o; a.ldo = C; a.sO = (long long)L * C;
+            a.B = n; a.H = 1; a.Lq = a.Lk = L; a.d = C;
+            a.scale = 1.0f / sqrtf((float)C);
+            ex.attention(a);
+        } else {
+            // any other width: three GEMMs around a row softmax over the materialised L x L scores
+            half_t* qk = ar.halfs(M * 2 * C);
+            {
+                GemmParams p;
+                p.A = g; p.lda = C; p.W = P(aw.q_w); p.ldw = C;
+                p.M = (int)M; p.N = 2 * C; p.K = C; p.bias_n = P(aw.q_b);
+                p.C = qk; p.ldc = 2 * C;
+                ex.gemm(p);
+            }
+            // key axis padded to a multiple of 8 (16-byte rows): pad keys get zero scores, zero probabilities and a finite V^T
+            // column (bias only), so any latent size works (63x63, 65x65 ...), as in the reference
+            const int Lp = (L + 7) & ~7;
+            half_t* vt = ar.halfs((size_t)n * C * Lp);
+            {   // V^T[b] = Wv · g_b^T + bv (bias along rows)
+                GemmParams p;
+                p.A = P(aw.v_w); p.lda = C; p.sA = 0;
+                p.W = g; p.ldw = C; p.sW = (long long)L * C;
+                p.M = C; p.N = Lp; p.n_valid = L; p.K = C; p.batch = n;
+                p.bias_m = P(aw.v_b);
+                p.C = vt; p.ldc = Lp; p.sC = (long long)C * Lp;
+                ex.gemm(p);
+            }
+            half_t* s = ar.halfs((size_t)n * L * Lp);
+            {   // S_b = Q_b K_b^T / sqrt(C)
+                GemmParams p;
+                p.A = qk; p.lda = 2 * C; p.sA = (long long)L * 2 * C;
+                p.W = qk + C; p.ldw = 2 * C; p.sW = (long long)L * 2 * C;
+                p.M = L; p.N = Lp; p.n_valid = L; p.K = C; p.batch = n;
+                p.alpha = 1.0f / sqrtf((float)C);
+                p.C = s; p.ldc = Lp; p.sC = (long long)L * Lp;
+                ex.gemm(p);
+            }
+            ex.launches += 1;
+            ex.t_begin(KC_MISC, 0.0, 1, "softmax", (long long)n * L, Lp, 0, 1);
+            if (!ex.dry && ex.status == LD_OK) ex.note(softmax_rows_launch(s, n * L, Lp, Lp, ex.stream, L));
+            ex.t_end("softmax_rows_kernel");
+            {   // O_b = P_b V_b  (W operand = V^T [C][Lp]; the pad keys carry zero probability)
+                GemmParams p;
+                p.A = s; p.lda = Lp; p.sA = (long long)L * Lp;
+                p.W = vt; p.ldw = Lp; p.sW = (long long)C * Lp;
+                p.M = L; p.N = C; p.K = Lp; p.batch = n;
+                p.C = o; p.ldc = C; p.sC = (long long)L * C;
+                ex.gemm(p);
+            }
         }
         {
             GemmParams p;

@@ -197,6 +197,40 @@ def test_attention_row_major_v(ops, b, heads, lq, lk, d):
         assert rel_l2(y.float().cpu(), ref) < TOL
 
 
+# One head of 512 (and 256) channels, V row-major: flash_attn512_kernel, the VAE's AttnBlock (LD.py:3591-3642) — 128-query workgroups whose wave
+# pairs split the channels and swap partial scores through LDS.  Whole and ragged tile counts (odd / even numbers of double-buffer flips),
+# query blocks that end mid-workgroup, cross shapes, the 63 x 63 / 65 x 65 latents of test_vae_latents_not_multiple_of_8, batch strides, and the fused
+# [q | k | v] form the VAE executor hands over.
+@pytest.mark.parametrize("b,lq,lk,d", [
+    (2, 4096, 4096, 512), (1, 256, 256, 512), (3, 160, 96, 512), (2, 100, 77, 512), (1, 3969, 3969, 512), (1, 4225, 4225, 512), (2, 33, 31, 512),
+    (1, 128, 32, 512), (2, 1024, 1024, 256), (2, 130, 200, 256), (1, 63, 63, 256)])
+def test_attention_one_wide_head(ops, b, lq, lk, d):
+    q, k, v = r16((b, lq, d), 61), r16((b, lk, d), 62), r16((b, lk, d), 63)
+    ref = O.attention(q.float(), k.float(), v.float(), 1)
+    y = ops.attention_rowv(q.to(DEV), k.to(DEV), v.to(DEV), 1)
+    assert rel_l2(y.float().cpu(), ref) < TOL
+    if lq == lk:
+        y = ops.attention_qkv(torch.cat([q, k, v], -1).to(DEV), 1)
+        assert rel_l2(y.float().cpu(), ref) < TOL
+
+
+def test_attention_one_wide_head_late_rescale_and_large_scores(ops):
+    """flash_attn512_kernel when the lazy softmax reference moves late and by a lot (both waves of a pair must move it identically — they
+    hold the same summed scores bit for bit), and with scores far from zero (the reference starts at the first tile's maximum)."""
+    b, l, d = 2, 1024, 512
+    q, k, v = r16((b, l, d), 64), r16((b, l, d), 65), r16((b, l, d), 66)
+    k[:, 900] = q[:, 3] * 3.0
+    k[:, 40] = q[:, 700] * 4.0
+    k[:, 1023] = q[:, 1023] * 5.0
+    k[:, :, :8] += 6.0                      # a common offset: every score of a query shifts by the same large amount
+    q[:, :, :8] += 2.0
+    ref = O.attention(q.float(), k.float(), v.float(), 1)
+    y = ops.attention_rowv(q.to(DEV), k.to(DEV), v.to(DEV), 1)
+    assert rel_l2(y.float().cpu(), ref) < TOL
+    for rows in ([3], [700], [1023]):
+        assert rel_l2(y[:, rows].float().cpu(), ref[:, rows]) < 2 * TOL
+
+
 def test_attention_rowv_late_rescale_branch(ops):
     """flash_attn2_kernel<3, rowV, plain, 8> (the d = 40 self-attention kernel the UNet runs) when the lazy softmax reference moves late:
     a few keys far larger than the rest in late tiles, for some queries only — O^T and the running sum have to be rescaled then."""
