@@ -1,6 +1,6 @@
-"""CLIP-L text conditioning (SURVEY §8 row a17): prompt-weight parsing, 77-token chunking, the 12-layer causal text
-transformer and the per-token weight lerp.  Runs once per prompt, so — as the scope table says — it stays on
-PyTorch-ROCm ops (no HIP kernels here); its output is the payload of the one RCCL broadcast.
+"""CLIP-L text conditioning (SURVEY §8 rows a17 / f2): prompt-weight parsing, 77-token chunking, the 12-layer causal text
+transformer (on the HIP kernels through the C ABI: `CLIPTextModelHIP`, the package's only text model) and the per-token weight
+lerp.  Runs once per prompt; its output is the payload of the one RCCL broadcast.
 
 Mirrors: token_weights / parse_parentheses (LD.py:4733-4780), SDTokenizer.tokenize_with_weights (LD.py:4936-5031),
 ClipTokenWeightEncoder.encode_token_weights (LD.py:4540-4569), SDClipModel.forward (LD.py:4692-4724),
@@ -8,11 +8,9 @@ CLIPTextModel_ (LD.py:4413-4463), CLIP.tokenize / encode_from_tokens / clip_laye
 """
 from __future__ import annotations
 
-import math
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
-import torch.nn.functional as F
 
 START_TOKEN, END_TOKEN = 49406, 49407
 _ESC_CLOSE, _ESC_OPEN = "\0\1", "\0\2"
@@ -118,57 +116,17 @@ class PromptTokenizer:
 
 
 # ------------------------------------------------------------------ text transformer
-class CLIPTextModel:
-    """Functional CLIP-L on a torch device, fp32 compute (the reference keeps fp16 weights but casts them to the fp32
-    activations per call — `manual_cast`, LD.py:2418-2429 — so the arithmetic is fp32)."""
-
-    def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], device="cuda:0", weight_dtype=torch.float32):
-        self.cfg, self.device = dict(cfg), torch.device(device)
-        self.w = {k: v.to(weight_dtype).to(self.device) for k, v in weights.items()}
-
-    def _lin(self, x, p):
-        return F.linear(x, self.w[p + ".weight"].float(), self.w[p + ".bias"].float())
-
-    def _ln(self, x, p):
-        return F.layer_norm(x, (x.shape[-1],), self.w[p + ".weight"].float(), self.w[p + ".bias"].float(), 1e-5)
-
-    @torch.no_grad()
-    def __call__(self, tokens: torch.Tensor, intermediate_output: Optional[int] = None):
-        """-> (last hidden state after final LN, final-LN'd hidden state after layer `intermediate_output` or None, pooled)."""
-        P = "text_model."
-        h, heads, nl = self.cfg["hidden_size"], self.cfg["num_attention_heads"], self.cfg["num_hidden_layers"]
-        tokens = tokens.to(self.device)
-        x = self.w[P + "embeddings.token_embedding.weight"].float()[tokens] + self.w[P + "embeddings.position_embedding.weight"].float()
-        L = x.shape[1]
-        mask = torch.full((L, L), float("-inf"), device=self.device).triu_(1)
-        stop = None if intermediate_output is None else (nl + intermediate_output if intermediate_output < 0 else intermediate_output)
-        inter = None
-        for i in range(nl):
-            p = f"{P}encoder.layers.{i}"
-            n = self._ln(x, p + ".layer_norm1")
-            q, k, v = (self._lin(n, f"{p}.self_attn.{t}_proj").view(-1, L, heads, h // heads).transpose(1, 2) for t in "qkv")
-            a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(h // heads) + mask, dim=-1) @ v
-            x = x + self._lin(a.transpose(1, 2).reshape(-1, L, h), p + ".self_attn.out_proj")
-            m = self._lin(self._ln(x, p + ".layer_norm2"), p + ".mlp.fc1")
-            x = x + self._lin(m * torch.sigmoid(1.702 * m), p + ".mlp.fc2")
-            if i == stop:
-                inter = x.clone()
-        x = self._ln(x, P + "final_layer_norm")
-        if inter is not None:
-            inter = self._ln(inter, P + "final_layer_norm")
-        pooled = x[torch.arange(x.shape[0], device=self.device), tokens.to(torch.int).argmax(dim=-1)]
-        return x, inter, pooled
-
-
-class CLIPTextModelHIP(CLIPTextModel):
-    """The same text transformer on the HIP kernels: LayerNorm, fused [q|k|v] projection, causal
+class CLIPTextModelHIP:
+    """CLIP-L text transformer (CLIPTextModel_, LD.py:4413-4463) on the HIP kernels — the package's ONLY text model
+    (the torch CPU restatement used by host-logic tests lives in oracle/sd15_ref.py: `clip_text_model`): LayerNorm, fused [q|k|v] projection, causal
     flash attention, out-projection + residual epilogue, fc1 + quick-GELU epilogue, fc2 + residual epilogue — all through
     the C ABI (`ops`), fp16 storage / fp32 accumulation.  Only the embedding gather (77 rows) and the final row pick for the
     pooled output stay torch indexing.  The reference computes this model in fp32; the conditioning it feeds is cast to
     fp16 by `apply_model` (LD.py:5846), so the tolerance here is the per-op fp16 one."""
 
     def __init__(self, cfg: dict, weights: Dict[str, torch.Tensor], device="cuda:0"):
-        super().__init__(cfg, weights, device, weight_dtype=torch.float16)
+        self.cfg, self.device = dict(cfg), torch.device(device)
+        self.w = {k: v.to(torch.float16).to(self.device) for k, v in weights.items()}
         P = "text_model.encoder.layers."
         self.qkv = []
         for i in range(cfg["num_hidden_layers"]):
@@ -209,7 +167,9 @@ class CLIPTextModelHIP(CLIPTextModel):
 class CLIP:
     """The object `CLIPTextEncode.encode(clip, text)` drives (LD.py:6222-6272)."""
 
-    def __init__(self, text_model: CLIPTextModel, tokenizer: Optional[PromptTokenizer] = None, layer_idx: Optional[int] = None):
+    def __init__(self, text_model, tokenizer: Optional[PromptTokenizer] = None, layer_idx: Optional[int] = None):
+        """text_model(tokens[B, 77] long, intermediate_output=layer_idx) -> (last hidden state, hidden state at layer_idx or None, pooled):
+        `CLIPTextModelHIP` in the product."""
         self.text_model, self.tokenizer, self.layer_idx = text_model, tokenizer, layer_idx
 
     def clone(self) -> "CLIP":

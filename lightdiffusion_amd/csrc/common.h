@@ -67,6 +67,11 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // beyond z = 6 the true tail is < 6e-9).  ONE transcendental (v_exp_f32) and 10 single-issue fp32 operations per value instead of two
 // transcendentals + 12 packed-fp32 operations per PAIR: a v_pk_*_f32 beside MFMAs costs ~3x two scalar operations (microarch guide,
 // 'price of one filler beside MFMAs'), and the GEGLU epilogues are vector-issue bound (40 GELUs per lane and tile).
+// NaN (accepted): min(|x|, 6) and max(x, 0) both return their non-NaN operand, so gelu(NaN) = -6 Phi(-6) ~ -6e-9 instead of
+// NaN — torch's erf form propagates it.  In the GEGLU product a NaN VALUE half still propagates (the final multiply), a NaN that reaches only
+// the GATE half is masked.  A NaN-transparent form (max(x, 0) as 0.5 (x + |x|)) costs one more vector instruction per value in an epilogue
+// that is vector-issue bound; the activations of this path are finite by construction (fp16 storage would have turned an overflow into inf,
+// which both forms handle alike: gelu(+inf) = +inf, gelu(-inf) = -0).
 #define LD_GELU_ZMAX 6.0f
 #define LD_GELU_C0 -0.999993086f
 #define LD_GELU_C1 -1.15120173f

@@ -691,13 +691,19 @@ int conv8_launch(const GemmParams& pin, hipStream_t stream) {
             (getenv("LD_C8_ABL") != nullptr ? atoi(getenv("LD_C8_ABL")) << 2 : 0);   // ablations (tools/conv8_abl.py; wrong results, timing only): 1 no fragment reads, 2 no MFMAs, 4 no halo staging, 8 no weight DMA in the loop
 #endif
     if (p.bias_n == nullptr || p.rowvec == nullptr || p.R == nullptr) {
-        static const half_t* zero_page = nullptr;
-        if (zero_page == nullptr) {
+        // the zero page is a __device__ symbol: one address PER DEVICE (a process that drives several GPUs must not hand device 1 the page of
+        // device 0), resolved once per device, thread-safe
+        constexpr int MAXDEV = 64;
+        static std::once_flag zonce[MAXDEV];
+        static const half_t* zpage[MAXDEV];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return LD_ERR_HIP;
+        std::call_once(zonce[dev], [&] {
             void* z = nullptr;
-            if (hipGetSymbolAddress(&z, HIP_SYMBOL(g_c8_zero)) != hipSuccess) return LD_ERR_HIP;
-            zero_page = static_cast<const half_t*>(z);
-        }
-        if (p.N > 8192) return LD_ERR_SHAPE;
+            zpage[dev] = hipGetSymbolAddress(&z, HIP_SYMBOL(g_c8_zero)) == hipSuccess ? static_cast<const half_t*>(z) : nullptr;
+        });
+        const half_t* zero_page = zpage[dev];
+        if (zero_page == nullptr) return LD_ERR_HIP;
         if (p.bias_n == nullptr) p.bias_n = zero_page;
         if (p.rowvec == nullptr) { p.rowvec = zero_page; p.ldrv = 0; p.rows_per_vec = 1; }
         if (p.R == nullptr) { p.R = zero_page; p.ldr = 0; }

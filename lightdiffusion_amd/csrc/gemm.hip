@@ -172,8 +172,10 @@ __device__ __forceinline__ void epilogue_tile(const GemmParams& p, const half_t*
         // Interior tiles without an activation: a branch-free path in PACKED fp16 (round 5; tools/gemm3_abl.py: with neither residual loads
         // nor stores the fp32 form of this path still took 4.6 of 23.5 us at 16384 x 640 x 640 — ~70 vector instructions per 16-byte chunk,
         // two workgroups per CU).  The bias is in the staged tile already (accumulator start value, or the LayerNorm-fold finish), so a chunk
-        // is: tile chunk (+ time-embedding row) (+ residual) by v_pk_add_f16 — the sum of two fp16 values is exact in fp32, so one packed add
-        // rounds exactly like the fp32 form did — and the LayerNorm-fold row statistics by v_dot2_f32_f16 on the packed result.
+        // is: tile chunk (+ time-embedding row) (+ residual) by v_pk_add_f16 — the sum of two fp16 values is exact in fp32, so ONE packed add
+        // rounds exactly like the fp32 form did; a chunk that takes both the row vector and the residual is rounded once more (two packed
+        // adds: round(round(tile + row) + residual), on top of the one rounding of acc * alpha + bias) — and the LayerNorm-fold row
+        // statistics by v_dot2_f32_f16 on the packed result.
         if (pre.fast) {
             static_assert(GRP == EpiPre<BM, BN>::GRP, "group size");
             half_t* Cb = p.C + (long long)z * p.sC + (long long)m0 * p.ldc + n0;
@@ -2573,8 +2575,10 @@ static bool two_wg_ok();   // (A/B hook, below)
 static bool m_fastest_ok();
 static bool skinny_conv1_ok();
 
+// conv1_2wg: gemm_launch's decision to run a 1x1 convolution on 64 x 64 tiles UNSPLIT on the two-workgroups-per-CU producer / consumer kernel
+// (its skinny_conv1 rule and the older few-tile rule behind the same A/B switch) — decided THERE, not re-derived here
 template <int BM, int BN>
-void launch_cfg(const GemmParams& p, hipStream_t s, bool deep = false) {
+void launch_cfg(const GemmParams& p, hipStream_t s, bool deep = false, bool conv1_2wg = false) {
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const int sk = p.splitk > 1 ? p.splitk : 1;
     dim3 grid(tiles * sk, 1, p.batch);
@@ -2592,7 +2596,7 @@ void launch_cfg(const GemmParams& p, hipStream_t s, bool deep = false) {
             hipLaunchKernelGGL((gemm4_kernel<64, 64, false, 4, 4>), grid, dim3(2 * NT), 0, s, p);
             return;
         }
-        if (p.conv && p.ksize == 1 && sk == 1 && blocks <= 512) {   // (gemm_launch's skinny_conv1 rule)
+        if (conv1_2wg) {
             t_last_kernel = "gemm4_kernel<64,64,conv,2wg>";
             hipLaunchKernelGGL((gemm4_kernel<64, 64, true, 4, 4>), grid, dim3(2 * NT), 0, s, p);
             return;
@@ -3096,7 +3100,10 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         p.m_fastest = (!p.conv && p.batch == 1 && tiles_m >= 2 && tiles_m <= 8 && (long long)p.N * p.K * 2 >= (8ll << 20) && m_fastest_ok()) ? 1 : 0;
     }
 
-    if (bn == 64) launch_cfg<64, 64>(p, stream);
+    // every unsplit 1x1 convolution that ends on 64 x 64 tiles with at most two workgroups per CU takes the 2wg kernel: the skinny_conv1 shapes
+    // and the few-tile shapes of the older skinny_max rule alike; A/B bit 8192 (skinny_conv1_ok) restores round 4's route for all of them
+    const bool conv1_2wg = bn == 64 && skinny_conv1_ok() && p.conv && p.ksize == 1 && sk <= 1 && (long long)tiles * p.batch <= 512;
+    if (bn == 64) launch_cfg<64, 64>(p, stream, false, conv1_2wg);
     else if (bm == 128 && bn == 160) launch_cfg<128, 160>(p, stream);
     else if (bm == 128 && bn == 128) launch_cfg<128, 128>(p, stream);
     else if (bm == 64 && bn == 160) launch_cfg<64, 160>(p, stream, deep);

@@ -19,7 +19,7 @@ import torch
 
 from . import sampling
 from . import weights as W
-from .clip import CLIP, CLIPTextModel, CLIPTextModelHIP, PromptTokenizer
+from .clip import CLIP, CLIPTextModelHIP, PromptTokenizer
 from .sampling import LATENT_SCALE, common_ksampler
 from .unet import MI355XUNet, MI355XVAE
 

@@ -46,11 +46,25 @@ def test_prompt_weights_and_chunking():
         assert all(len(c) == 77 and c[0][0] == 49406 for c in got)
 
 
+class _OracleTextModel:
+    """The text-model callable `clip.CLIP` drives, built from the oracle's CPU restatement (the package itself only has the HIP one)."""
+
+    def __init__(self, cfg, sd):
+        self.cfg, self.sd = cfg, sd
+
+    def __call__(self, tokens, intermediate_output=None):
+        from oracle import sd15_ref as O
+        last = O.clip_text_model(self.sd, self.cfg, tokens, layer_idx=None)
+        inter = None if intermediate_output is None else O.clip_text_model(self.sd, self.cfg, tokens, layer_idx=intermediate_output)
+        pooled = last[torch.arange(last.shape[0]), tokens.to(torch.int).argmax(dim=-1)]
+        return last, inter, pooled
+
+
 def test_clip_text_model_and_weight_lerp():
-    from lightdiffusion_amd.clip import CLIP, CLIPTextModel
+    from lightdiffusion_amd.clip import CLIP
     g = load_golden("clip_tiny")
     cfg = W.tiny_clip_config()
-    tm = CLIPTextModel(cfg, W.synth_state_dict(W.clip_param_shapes(cfg)), device="cpu")
+    tm = _OracleTextModel(cfg, W.synth_state_dict(W.clip_param_shapes(cfg)))
     last, inter, pooled = tm(g["tokens"], intermediate_output=-2)
     assert rel_l2(last, g["last"]) < 5e-6 and rel_l2(inter, g["inter_m2"]) < 5e-6 and rel_l2(pooled, g["pooled"]) < 5e-6
     clip = CLIP(tm, None, layer_idx=-2)
