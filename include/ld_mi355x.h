@@ -110,6 +110,9 @@ int ld_vae_param_info(const ld_vae* v, int index, const char** name, int* ndim, 
 int ld_vae_load_param(ld_vae* v, const char* name, const void* dev_src, int dtype, void* stream);
 int ld_vae_reserve(ld_vae* v, int max_b, int max_h, int max_w);   /* latent size */
 size_t ld_vae_workspace_bytes(const ld_vae* v);
+/* workspace bytes ld_vae_reserve(b, h, w) would allocate (host-only dry run, nothing is allocated; 0 on an invalid shape): lets the host
+ * split a batch by free device memory the way VAE.decode does (LD.py:6357-6362) */
+size_t ld_vae_plan_bytes(ld_vae* v, int b, int h, int w);
 /* z: [b][z_channels][h][w] fp32 (already divided by 0.18215); out: [b][8h][8w][3] fp32 in [0,1] */
 int ld_vae_decode(ld_vae* v, const float* z, float* out, int b, int h, int w, void* stream);
 /* VAE.encode's device part (LD.py:6383-6410): pixels fp32 NCHW [b][3][8h][8w] in [-1,1] -> moments fp32 NCHW [b][2z][h][w]

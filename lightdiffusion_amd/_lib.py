@@ -65,6 +65,7 @@ SIGNATURES = {
     "ld_vae_load_param": (_I, [_P, C.c_char_p, _P, _I, _P]),
     "ld_vae_reserve": (_I, [_P, _I, _I, _I]),
     "ld_vae_workspace_bytes": (_Z, [_P]),
+    "ld_vae_plan_bytes": (_Z, [_P, _I, _I, _I]),
     "ld_vae_decode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ld_vae_encode": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "ld_vae_profile": (_I, [_P, _P, _P, _I, _I, _I, _P]),

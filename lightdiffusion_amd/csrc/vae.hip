@@ -592,6 +592,20 @@ int ld_vae_reserve(ld_vae* v, int max_b, int max_h, int max_w) {
     return LD_OK;
 }
 
+size_t ld_vae_plan_bytes(ld_vae* v, int b, int h, int w) {
+    // host-only dry run of the executor: the workspace a (b, h, w) decode (and encode, when the encoder is loaded) needs, without allocating
+    if (v == nullptr || b < 1 || h < 1 || w < 1) return 0;
+    size_t peak = 0;
+    if (run_decode(v, true, nullptr, nullptr, b, h, w, nullptr, &peak) != LD_OK) return 0;
+    if (v->cfg.with_encoder) {
+        size_t pe = 0;
+        if (run_encode(v, true, nullptr, nullptr, b, h, w, nullptr, &pe) != LD_OK) return 0;
+        if (pe > peak) peak = pe;
+    }
+    v->plan_b = v->plan_h = v->plan_w = 0;          // (the dry run re-planned the arena marks: the next real call plans its own shape)
+    return (peak + 4095) / 4096 * 4096 + ((size_t)96 << 20) + 4096;
+}
+
 int ld_vae_decode(ld_vae* v, const float* z, float* out, int b, int h, int w, void* stream) {
     if (v == nullptr || z == nullptr || out == nullptr) return LD_ERR_ARG;
     if (v->ws_base == nullptr || !v->pt.all_loaded()) return LD_ERR_STATE;

@@ -387,13 +387,37 @@ class MI355XVAE:
     def last_launches(self) -> int:
         return lib().ld_vae_last_launches(self._h)
 
+    memory_fraction = 0.9          # share of the free device memory a decode's workspace may take
+    memory_budget = None           # bytes; None: ask the driver (torch.cuda.mem_get_info) — tests set it to force the split
+
+    def batch_number(self, b: int, h: int, w: int) -> int:
+        """VAE.decode's split of the batch by free memory (LD.py:6357-6362: batch_number = free_memory / memory_used): the largest slice
+        of the batch whose planned workspace (`ld_vae_plan_bytes`, a host-only dry run of the executor) fits the budget; at least 1."""
+        mb, mh, mw = self._reserved
+        if b <= mb and h <= mh and w <= mw:
+            return b                                              # fits the workspace that is already there
+        budget = self.memory_budget
+        if budget is None:
+            free, _ = torch.cuda.mem_get_info(self.device)
+            budget = self.memory_fraction * (free + (self.workspace_bytes if any(self._reserved) else 0))   # (a re-reserve frees the old one first)
+        n = b
+        while n > 1:
+            need = lib().ld_vae_plan_bytes(self._h, n, max(h, mh), max(w, mw))
+            if 0 < need <= budget:
+                break
+            n = (n + 1) // 2
+        return n
+
     def decode_device(self, z: torch.Tensor) -> torch.Tensor:
         z = z.to(self.device, torch.float32).contiguous()
         b, _, h, w = z.shape
-        self._ensure(b, h, w)
+        n = self.batch_number(b, h, w)
+        self._ensure(n, h, w)
         out = torch.empty(b, 8 * h, 8 * w, self.cfg["out_ch"], dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            check(lib().ld_vae_decode(self._h, z.data_ptr(), out.data_ptr(), b, h, w, _stream()), "ld_vae_decode")
+            for x in range(0, b, n):                              # (one slice when everything fits: the usual case with 288 GB)
+                m = min(n, b - x)
+                check(lib().ld_vae_decode(self._h, z[x:x + m].data_ptr(), out[x:x + m].data_ptr(), m, h, w, _stream()), "ld_vae_decode")
         return out
 
     def profile_decode(self, z: torch.Tensor) -> list:

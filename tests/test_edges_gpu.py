@@ -120,3 +120,26 @@ def test_vae_odd_and_batch():
         img = v.decode(z)
         ref = O.vae_decode(sdv, cfg, z)
         assert img.shape == ref.shape and float((img - ref).abs().max()) < 2.0 / 255.0
+
+
+def test_vae_decode_splits_the_batch_by_memory():
+    """VAE.decode decodes the batch in slices that fit the free memory (LD.py:6357-6381).  With a budget that holds one image of a batch of
+    three the decode runs as three slices and gives the whole-batch result (rounding follows the batch: tile choices); the plan query itself
+    grows with the batch and allocates nothing."""
+    from lightdiffusion_amd import weights as W
+    from lightdiffusion_amd._lib import lib
+    from lightdiffusion_amd.unet import synthetic_vae
+    cfg = W.tiny_vae_config()
+    z = torch.randn(3, 4, 16, 24, generator=torch.Generator().manual_seed(8))
+    whole = synthetic_vae(cfg, max_batch=3, max_hw=(16, 24)).decode(z)
+    vae = synthetic_vae(cfg, max_batch=1, max_hw=(8, 8))
+    ws0 = vae.workspace_bytes
+    need1, need3 = (lib().ld_vae_plan_bytes(vae._h, n, 16, 24) for n in (1, 3))
+    assert 0 < need1 < need3 and vae.workspace_bytes == ws0
+    vae.memory_budget = need1 + 1024
+    assert vae.batch_number(3, 16, 24) == 1
+    sliced = vae.decode(z)
+    assert vae._reserved[0] == 1 and sliced.shape == whole.shape
+    assert float((sliced - whole).abs().max()) < 2.0 / 255.0
+    vae.memory_budget = None                               # the real free memory holds all three
+    assert vae.batch_number(3, 16, 24) == 3
