@@ -53,6 +53,36 @@ def test_config3_unet_batch16_64x64(sd15_unet):
     assert rel_l2(den[0], den[3]) < 1e-3 and rel_l2(den[1], den[2]) < 1e-3
 
 
+def test_config3_through_the_wrapper_hook_at_batch16(sd15_unet):
+    """The reference's own seam at config #3's size (UNet batch 16, 64 x 64): `MI355XUNet.__call__` replays captured hipGraphs.  Sixteen
+    different samples under cond_or_uncond == [1, 0]: the speculative CFG-pair replay is found wrong ON THE DEVICE (halves differ) and the
+    call itself replays the plain graph — every row must reproduce the reference golden of its sample.  Then the shape calc_cond_batch really
+    sends (one latent batch twice): the pair graph, bit for bit the eager `ld_unet_forward_pair`, and its cond rows against the golden."""
+    g = load_golden("unet_sd15_64x64")
+    order = [0, 1, 1, 0, 0, 0, 1, 1, 1, 0, 1, 0, 0, 1, 1, 0]
+    x, s, ctx = _stack(g, order)
+    mk = lambda xx, ss, cc: {"input": xx.to(DEV), "timestep": ss.to(DEV), "c": {"c_crossattn": cc.to(DEV), "transformer_options": {"cond_or_uncond": [1, 0]}},
+                             "cond_or_uncond": [1, 0]}
+    sd15_unet._hook.clear()
+    den = sd15_unet(None, mk(x, s, ctx)).cpu()
+    run = sd15_unet._hook[(16, 64, 64)]
+    assert run.halves_differed and run.plain.graph is not None
+    for row, src in enumerate(order):
+        assert rel_l2(den[row], g["denoised"][src]) < UNET_TOL, row
+    # what the reference sends: cat([x_in, x_in]) against cat([uncond, cond]); row i of the cond half = golden sample order[i] when its
+    # context row is that sample's
+    sd15_unet._hook.clear()
+    x8, s8 = x[:8], s[:8]
+    ctx2 = torch.cat([ctx[8:], ctx[:8]])                      # uncond half: some other context; cond half: the rows' own contexts
+    out = sd15_unet(None, mk(torch.cat([x8, x8]), torch.cat([s8, s8]), ctx2))
+    run = sd15_unet._hook[(16, 64, 64)]
+    assert run.pair.graph is not None and not run.halves_differed and run.plain.graph is None
+    assert torch.equal(out, sd15_unet.forward_pair(x8.to(DEV).contiguous(), s8.to(DEV).contiguous()))
+    for row in range(8):
+        assert rel_l2(out[8 + row].cpu(), g["denoised"][order[row]]) < UNET_TOL, row
+    sd15_unet._hook.clear()
+
+
 @pytest.mark.parametrize("n", [2, 8])
 def test_config5_unet_128x128(sd15_unet, n):
     """Config #5 (hires-fix, batch 4 => UNet batch 8 at 128x128 latents, self-attention over L = 16384 tokens) against the
