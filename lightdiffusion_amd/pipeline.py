@@ -61,10 +61,11 @@ class CFGDenoiser:
         self.unet, self.batch, self.cfg_scale = unet, batch, float(cfg_scale)
         dev = unet.device
         c = unet.cfg["in_channels"]
-        self.x1 = torch.zeros(batch, c, h, w, dtype=torch.float32, device=dev)
-        self.sigma1 = torch.ones(batch, dtype=torch.float32, device=dev)
-        self.den2 = torch.zeros(2 * batch, c, h, w, dtype=torch.float32, device=dev)
-        self.den = torch.zeros(batch, c, h, w, dtype=torch.float32, device=dev)
+        with torch.inference_mode(False):      # static buffers are plain tensors whatever mode the first call came in (the reference calls
+            self.x1 = torch.zeros(batch, c, h, w, dtype=torch.float32, device=dev)          # under torch.inference_mode(), LD.py:10493: buffers
+            self.sigma1 = torch.ones(batch, dtype=torch.float32, device=dev)                # created there could not be updated in place by a
+            self.den2 = torch.zeros(2 * batch, c, h, w, dtype=torch.float32, device=dev)    # later call outside it)
+            self.den = torch.zeros(batch, c, h, w, dtype=torch.float32, device=dev)
         self.use_graph = use_graph
         self._run = GraphedBody(unet, self._body, use_graph)
 
@@ -114,9 +115,10 @@ class HookRunner:
         dev = unet.device
         c = unet.cfg["in_channels"]
         self.unet, self.n = unet, n
-        self.x = torch.zeros(n, c, h, w, dtype=torch.float32, device=dev)
-        self.sigma = torch.ones(n, dtype=torch.float32, device=dev)
-        self.out = torch.zeros(n, c, h, w, dtype=torch.float32, device=dev)
+        with torch.inference_mode(False):      # (plain tensors: see CFGDenoiser)
+            self.x = torch.zeros(n, c, h, w, dtype=torch.float32, device=dev)
+            self.sigma = torch.ones(n, dtype=torch.float32, device=dev)
+            self.out = torch.zeros(n, c, h, w, dtype=torch.float32, device=dev)
         self.plain = GraphedBody(unet, lambda: unet.forward(self.x, self.sigma, out=self.out))
         half = n // 2
         self.pair = GraphedBody(unet, lambda: unet.forward_pair(self.x[:half], self.sigma[:half], out=self.out)) if n % 2 == 0 and n else None

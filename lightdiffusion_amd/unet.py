@@ -271,7 +271,8 @@ class MI355XUNet:
         known = self._ctx_ref is not None and self._ctx_ref.shape == c.shape and self._ctx_ref.dtype == c.dtype
         if not known:                                  # first call, or another number of tokens / rows: nothing to speculate on
             self.set_context(c)
-            self._ctx_ref = c.clone()
+            with torch.inference_mode(False):          # (a plain tensor: later calls update it in place, inside or outside inference mode)
+                self._ctx_ref = c.clone()
         key = (n, h, w)
         run = self._hook.get(key)
         if run is None:
@@ -279,7 +280,8 @@ class MI355XUNet:
                 self._hook.pop(next(iter(self._hook)))
             run = self._hook[key] = HookRunner(self, n, h, w)
         if self._hook_flags is None:
-            self._hook_flags = torch.zeros(2, dtype=torch.int32).pin_memory()
+            with torch.inference_mode(False):
+                self._hook_flags = torch.zeros(2, dtype=torch.int32).pin_memory()
             self._hook_event = torch.cuda.Event()
         pair = run.pair is not None and cond_or_uncond is not None and list(cond_or_uncond) == [1, 0] and not run.halves_differed
         self._hook_epoch += 1

@@ -153,6 +153,25 @@ def test_wrapper_hook_replays_graphs_bitwise_and_follows_the_prompt(tiny_unet):
     assert run.halves_differed and run.plain.graph is not None
     assert torch.equal(out2, tiny_unet.forward(x2, s))
     assert rel_l2(out2.cpu(), O.apply_model(sd, cfg, ms, x2.cpu(), s.cpu(), ctx.cpu())) < UNET_TOL
+    # the reference calls the wrapper from a daemon worker thread under torch.inference_mode() (LD.py:10453, 10493): first contact there
+    # (buffers, capture), then the same call from the main thread in normal mode — same bits both ways
+    import threading
+    tiny_unet._hook.clear()
+    tiny_unet._ctx_ref = None
+    box = {}
+
+    def worker():
+        try:
+            with torch.inference_mode():
+                box["out"] = tiny_unet(None, mk(x, ctx.clone())).clone()
+        except Exception as e:      # noqa: BLE001 (re-raised on the main thread)
+            box["err"] = e
+
+    th = threading.Thread(target=worker, daemon=True)
+    th.start()
+    th.join()
+    assert "err" not in box, box.get("err")
+    assert torch.equal(box["out"], out) and torch.equal(tiny_unet(None, mk(x, ctx.clone())), out)
     # eager switch (A/B) and unload: .to("cpu") drops the captured graphs like the reference's graph-mode plugin does (LD.py:9921-9933)
     tiny_unet.hook_graph = False
     try:

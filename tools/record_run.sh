@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-5 record run: full -m gpu suite, bench lines (default and driver-style), launch tables.  Usage (gpurun): bash tools/record_run.sh <tag>
+# record run of a round (r05, r06, ...): full -m gpu suite, bench lines (default and driver-style), launch tables.  Usage (gpurun): bash tools/record_run.sh <tag>
 TAG=${1:-r05}
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/${TAG}_gpu_tests.log 2>&1
