@@ -1079,16 +1079,8 @@ constexpr int V5_SWZ = 0x78;                         // g[x] = (0x78 >> 2x) & 3 
 // EPI (compile time: one epilogue per kernel instantiation keeps its code and its register demand small — with all three inlined
 // into one kernel hipcc spilled 160 registers there and the LayerNorm-folded GEGLU of level 2 ran at 234 us instead of 140):
 //   0 plain (bias / row vector / activation / residual), 1 plain + LayerNorm-fold statistics out, 2 GEGLU
-template <int EPI, bool GNE = false>
-// ga (round 6): GroupNorm partial statistics of the OUTPUT for N = 320 (10 channels per group), accumulated by the plain packed path when `gne`:
-// a lane's five chunk slots q = lane + 64 k keep their chunk column over the four strips of a wave tile, and a chunk of 8 channels holds
-// at most two groups with the boundary between channel PAIRS (after 1, 2 or 3 pairs by the column's position in the 40-channel period), so
-// the running v_dot2 prefix over the four pairs gives both parts {sum, sum of squares of the first part; of the second part}.  Twenty
-// accumulator registers next to the 80 accumulators of the strips still waiting made hipcc spill 200 VGPRs, so nothing is kept per slot:
-// the slot's four values go straight to LDS (the strip's own area: its chunks are in registers by then, and a wave's LDS operations execute
-// in order), lanes 0..19 add up the 16 rows of their chunk column and keep ONE f32x4 (gt) over the four strips.
-__device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* Cs, int z, int m_base, int n_base, int lane, int part, bool bias_done,
-                                                  bool gne, f32x4& gt) {
+template <int EPI>
+__device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* Cs, int z, int m_base, int n_base, int lane, int part, bool bias_done) {
     const bool rows_full = m_base + 16 <= p.M;                          // (wave-uniform) every row of the strip exists: the branch-free paths
     // (GEGLU keeps the predicated loop: with 40 accumulators of the next strips still live, the batched / interleaved form of the 128 x 160
     // kernel's epilogue spills here and measured 14 % slower per launch at 4096 x 10240 x 1280)
@@ -1184,19 +1176,6 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
             if (hv) packed = add8h(packed, rv[k]);
             if (hr) packed = add8h(packed, rres[k]);
             st16(Cb + (long long)row * p.ldc + cc * 8, packed);
-            if (GNE && EPI == 0 && gne) {
-                const half2v one2 = {(half_t)1.f, (half_t)1.f};
-                const half2v h0 = __builtin_bit_cast(half2v, packed.x), h1 = __builtin_bit_cast(half2v, packed.y);
-                const half2v h2 = __builtin_bit_cast(half2v, packed.z), h3 = __builtin_bit_cast(half2v, packed.w);
-                const float p1 = __builtin_amdgcn_fdot2(h0, one2, 0.f, false), p2 = __builtin_amdgcn_fdot2(h1, one2, p1, false);
-                const float p3 = __builtin_amdgcn_fdot2(h2, one2, p2, false), p4 = __builtin_amdgcn_fdot2(h3, one2, p3, false);
-                const float q1 = __builtin_amdgcn_fdot2(h0, h0, 0.f, false), q2 = __builtin_amdgcn_fdot2(h1, h1, q1, false);
-                const float q3 = __builtin_amdgcn_fdot2(h2, h2, q2, false), q4 = __builtin_amdgcn_fdot2(h3, h3, q3, false);
-                const int ty = cc % 5;                          // pairs of the chunk's FIRST group: 4, 1, 2, 3, 4 at positions 0 .. 4 of the period
-                const float a1 = ty == 1 ? p1 : ty == 2 ? p2 : ty == 3 ? p3 : p4;
-                const float a2 = ty == 1 ? q1 : ty == 2 ? q2 : ty == 3 ? q3 : q4;
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(Cs) + q * 4) = (f32x4){a1, a2, p4 - a1, q4 - a2};
-            }
             if (EPI == 1 && p.stat_out != nullptr) {   // LN-fold producer: row statistics of the stored fp16 values
                 const half2v one2 = {(half_t)1.f, (half_t)1.f};
                 const half2v h0 = __builtin_bit_cast(half2v, packed.x), h1 = __builtin_bit_cast(half2v, packed.y);
@@ -1206,15 +1185,6 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
                 s1[k] = __builtin_amdgcn_fdot2(h3, one2, __builtin_amdgcn_fdot2(h2, one2, a1, false), false);
                 s2[k] = __builtin_amdgcn_fdot2(h3, h3, __builtin_amdgcn_fdot2(h2, h2, a2, false), false);
             }
-        }
-        if (GNE && EPI == 0 && gne) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane < 20) {
-                const float* sc = reinterpret_cast<const float*>(Cs);
-#pragma unroll 4
-                for (int r = 0; r < 16; ++r) gt += *reinterpret_cast<const f32x4*>(sc + (r * 20 + lane) * 4);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the strip area is re-staged next)
         }
         if (EPI == 1 && p.stat_out != nullptr) {   // chunk partials -> LDS (the strip has been consumed) -> one lane per row, in chunk order
             float* sc = reinterpret_cast<float*>(Cs);
@@ -1307,9 +1277,9 @@ __device__ __forceinline__ void v5_epilogue_strip(const GemmParams& p, half_t* C
 
 // tail shared by the 256 x 320 tile kernels (v5 / v6): split-K slab store, or the staged fused epilogue (two 16-row strips at a
 // time through this wave's 10.5 KB of the — by now quiet — LDS ring)
-template <int EPI, bool LNC, bool GNE = false>   // EPI: see v5_epilogue_strip; LNC: LayerNorm-fold consumer (ln_mu / ln_rs valid); GNE: may be asked for GroupNorm partials (conv6 only)
+template <int EPI, bool LNC>   // EPI: see v5_epilogue_strip; LNC: LayerNorm-fold consumer (ln_mu / ln_rs valid)
 __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][10], char* smem5, const float* ln_mu, const float* ln_rs, int z, int m0,
-                                          int n0, int wm0, int wn0, int wid, int lane, int ks, int splitk, int tn_i, int gimg = 0, int gchunk = 0) {
+                                          int n0, int wm0, int wn0, int wid, int lane, int ks, int splitk, int tn_i) {
     constexpr int TM = 4, TN = 10;
     const int fr = lane & 15, fq = lane >> 4;
     const int m_w = m0 + wm0, n_w = n0 + wn0;
@@ -1363,55 +1333,20 @@ __device__ __forceinline__ void v5_finish(const GemmParams& p, f32x4 (&acc)[4][1
         }
     };
     half_t* Cs1 = Cs + 16 * V5_EPI_LD;
-    // GroupNorm partial statistics of the output (GemmParams::gn_part; workgroup-uniform, host-checked: N == 320, whole tiles of one image,
-    // the plain packed epilogue): see v5_epilogue_strip
-    const bool gne = GNE && EPI == 0 && p.gn_part != nullptr;
-    f32x4 ga = {0.f, 0.f, 0.f, 0.f};                               // lanes 0..19: their chunk column's sums over the wave tile's 64 rows
     stage(std::integral_constant<int, 0>{}, Cs);
     stage(std::integral_constant<int, 1>{}, Cs1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // same wave, in-order LDS: the strips are complete
     __builtin_amdgcn_sched_barrier(0);
-    v5_epilogue_strip<EPI, GNE>(p, Cs, z, m_w, n_w, lane, part, bias_done, gne, ga);
-    v5_epilogue_strip<EPI, GNE>(p, Cs1, z, m_w + 16, n_w, lane, part, bias_done, gne, ga);
+    v5_epilogue_strip<EPI>(p, Cs, z, m_w, n_w, lane, part, bias_done);
+    v5_epilogue_strip<EPI>(p, Cs1, z, m_w + 16, n_w, lane, part, bias_done);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // strips consumed before the next pair overwrites them
     __builtin_amdgcn_sched_barrier(0);
     stage(std::integral_constant<int, 2>{}, Cs);
     stage(std::integral_constant<int, 3>{}, Cs1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    v5_epilogue_strip<EPI, GNE>(p, Cs, z, m_w + 32, n_w, lane, part, bias_done, gne, ga);
-    v5_epilogue_strip<EPI, GNE>(p, Cs1, z, m_w + 48, n_w, lane, part, bias_done, gne, ga);
-    if (GNE && EPI == 0 && gne) {
-        // per wave: the 320 (row, chunk column) slots of its strips -> 20 chunk columns (one lane each, rows top to bottom) -> its 16 groups;
-        // per workgroup: the four waves of a column half top to bottom (fixed order everywhere: bitwise reproducible)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the last strips have been consumed: the wave's strip area is free
-        float* ws = reinterpret_cast<float*>(Cs);
-        if (lane < 20) *reinterpret_cast<f32x4*>(ws + (320 + lane) * 4) = ga;   // chunk column sums
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        float* wp = reinterpret_cast<float*>(smem5 + 8 * 2 * V5_EPI_BYTES);     // [8 waves][16 groups][2], behind every wave's strips
-        if (lane < 16) {
-            // group g = 4 m + j of the wave's 160 columns: j = 0: first parts of columns 5m, 5m + 1; j > 0: second part of 5m + j, first part of 5m + j + 1
-            const int m = lane >> 2, j = lane & 3;
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(ws + (320 + 5 * m + j) * 4);
-            const f32x4 c1 = *reinterpret_cast<const f32x4*>(ws + (320 + 5 * m + j + 1) * 4);
-            const float s1 = (j == 0 ? c0[0] : c0[2]) + c1[0], s2 = (j == 0 ? c0[1] : c0[3]) + c1[1];
-            *reinterpret_cast<float2*>(wp + (wid * 16 + lane) * 2) = make_float2(s1, s2);
-        }
-        __syncthreads();
-        const int tid = wid * 64 + lane;
-        if (tid < 32) {
-            const int wn = tid >> 4, g = tid & 15;
-            float s = 0.f, ss = 0.f;
-            for (int wmi = 0; wmi < 4; ++wmi) {
-                const float* e = wp + ((wmi * 2 + wn) * 16 + g) * 2;
-                s += e[0];
-                ss += e[1];
-            }
-            float* o = p.gn_part + (((long long)gimg * p.gn_P + gchunk) * 32 + tid) * 2;
-            o[0] = s;
-            o[1] = ss;
-        }
-    }
+    v5_epilogue_strip<EPI>(p, Cs, z, m_w + 32, n_w, lane, part, bias_done);
+    v5_epilogue_strip<EPI>(p, Cs1, z, m_w + 48, n_w, lane, part, bias_done);
 }
 
 // Epilogue of the halo-tile kernel's narrower tiles (256 x 256: the VAE's N = 256 / 512 convolutions; written for any width 16 TN per
@@ -2081,7 +2016,7 @@ __global__ __launch_bounds__(512, 2) void conv6_kernel(const GemmParams p) {
     }
     if (!grp1) __builtin_amdgcn_s_barrier();                            // group 0 waits out group 1's last MFMA phase
     if (GN) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the asm MFMAs are invisible to hipcc's hazard recogniser: let the last ones retire before VALU reads the accumulators
-    if constexpr (BN == V5_BN) v5_finish<0, false, true>(p, acc, smem5, nullptr, nullptr, 0, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i, img, t_in);
+    if constexpr (BN == V5_BN) v5_finish<0, false>(p, acc, smem5, nullptr, nullptr, 0, m0, n0, wm0, wn0, wid, lane, ks, splitk, tn_i);
     else v6_finish<TM, TN>(p, acc, smem5, m0, n0, wm0, wn0, wid, lane, ks, splitk, img, t_in);
 }
 
@@ -2930,9 +2865,7 @@ int gemm_launch(const GemmParams& pin, hipStream_t stream) {
         if (sk6 == 1 && p.gn_part != nullptr) {
             // the generic epilogue (v6_finish) also writes the GroupNorm partial statistics of the OUTPUT, one chunk per tile of an image
             const int cpg = p.N / 32, tiles_img = (p.Ho / (pl.bm / wc)) * (p.Wo / wc);
-            // ... and so does the 256 x 320 tile's epilogue (v5_finish, round 6) for N = 320 — the UNet's level 0: groups of 10 channels
-            const bool ok320 = bn6 == V5_BN && p.N == V5_BN && p.n_valid == p.N && p.act == 0 && p.bias_m == nullptr && p.M % pl.bm == 0;
-            const bool ok = ok320 || ((bn6 == 256 || bn6 == 128) && p.N % 32 == 0 && (p.N == 128 || cpg % 8 == 0) && bn6 % cpg == 0 && p.n_valid == p.N && p.act == 0);
+            const bool ok = (bn6 == 256 || bn6 == 128) && p.N % 32 == 0 && (p.N == 128 || cpg % 8 == 0) && bn6 % cpg == 0 && p.n_valid == p.N && p.act == 0;
             if (ok) {
                 p.gn_P = tiles_img;
                 if (p.gn_part_done != nullptr) *p.gn_part_done = tiles_img;

@@ -104,7 +104,7 @@ def test_conv_row_resident(ops, n, hw, cin, cout, up, rv, res):
 
 
 # GroupNorm partial statistics written by the PRODUCING convolution (so the GroupNorm that follows runs one pass): every kernel that writes
-# them — the halo convolution's 256 x 320 tile at N = 320 (the UNet's level 0), its generic epilogue at 256- and 128-column tiles (the VAE decoder's stages, LD.py:3560-3576; also behind the
+# them — the halo convolution's generic epilogue at 256- and 128-column tiles (the VAE decoder's stages, LD.py:3560-3576; also behind the
 # nearest-2x upsampling), the row-resident kernel (two-image levels of the UNet) and the split-K second pass (8 x 8 level at UNet batch 16).
 # Checked against the statistics of the tensor the kernel stored: per (image, group) sum and sum of squares over all chunks, in fp64.
 @pytest.mark.parametrize("n,hw,cin,cout,up,res,expect", [
@@ -112,8 +112,8 @@ def test_conv_row_resident(ops, n, hw, cin, cout, up, rv, res):
     (4, 128, 256, 256, False, False, True),      # conv6 <W128, 256>: 8-channel groups
     (2, 256, 128, 128, False, True, True),       # conv6 <W128, 128 x 512 tiles>: 4-channel groups, two per chunk; image cut into 128-pixel bands
     (4, 128, 256, 256, True, False, True),       # ... behind the nearest-2x upsampling (64 -> 128)
-    (16, 64, 320, 320, False, True, True),       # conv6 <W64, 320-column tile> (round 6, the UNet's level 0 at batch 16): 10-channel groups, the boundary inside an 8-channel chunk
-    (4, 128, 640, 320, False, False, True),      # conv6 <W128, 320>: the hires pass's level 0, K = 5760
+    (16, 64, 320, 320, False, True, None),       # conv6 <W64, 320-column tile> (the UNet's level 0 at batch 16; 10-channel groups): no partials from its epilogue today
+    (4, 128, 640, 320, False, False, None),      # (round 6 built them — tools/experiments/gn_partials_v5_epilogue_n320_r06.patch.txt — and measured +-0 per forward); either way exact
     (2, 16, 1280, 1280, False, True, True),      # conv8: 16-pixel chunks
     (2, 64, 320, 320, False, False, True),       # conv8 at 64 x 64
     (16, 8, 1280, 1280, False, True, True),      # 128 x 160 kernel + split-K reduce with GroupNorm partials
