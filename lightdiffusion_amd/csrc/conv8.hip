@@ -669,6 +669,11 @@ bool conv8_plan(const GemmParams& p, int* S_out) {
     const long long tiles = (long long)tms * ntn;
     if (tiles > 256 || tiles * 4 > LD_SYNC_INTS) return false;
     int S = (int)(256 / tiles);
+    // round 6 (tools/conv8_slab_sweep.py, profiles/r06_conv8_slab_sweep.txt: the batch-1 forward per image width and slab count): the plan is at
+    // the optimum at 64 / 32 / 16 pixels (S = 1 / 2 / 4; one more doubling costs 0.11 - 0.17 ms, one less 0.2 - 0.7 ms), but the 8 x 8 level
+    // (16 tiles -> S = 16, one workgroup per CU) is faster with 8 deeper slabs on half the CUs: 5.169 -> 5.122 ms — sixteen fp32 partials per
+    // output meet in HBM where eight do
+    if (S > 8) S = 8;
     if (S > nsub / 2) S = nsub / 2;                                       // at least two sub-slabs per workgroup
     while (S > 1 && (size_t)S * p.M * p.N * sizeof(float) > p.partial_bytes) --S;
     if (S < 1 || (size_t)p.M * p.N * sizeof(float) > p.partial_bytes) return false;
@@ -684,6 +689,23 @@ int conv8_launch(const GemmParams& pin, hipStream_t stream) {
     GemmParams p = pin;
     int S = 0;
     if (!conv8_plan(p, &S)) return LD_ERR_ARG;
+#ifdef LD_AB_BUILD
+    {   // slab-count sweep (tools/conv8_slab_sweep.py): LD_C8_S_W<width> = number of channel slabs per tile for that image width
+        static const char* names[4] = {"LD_C8_S_W8", "LD_C8_S_W16", "LD_C8_S_W32", "LD_C8_S_W64"};
+        const char* e = getenv(names[p.Wo == 8 ? 0 : p.Wo == 16 ? 1 : p.Wo == 32 ? 2 : 3]);
+        if (e != nullptr) {
+            int want = atoi(e);
+            const int nsub = (p.C1 + p.C2) / 16;
+            const long long tiles = (long long)(p.M / 128) * (p.N / C8_BN);
+            if (want < 1) want = 1;
+            if (want > 16) want = 16;                                      // (the reducer's generic path sums up to 16 slabs)
+            if (want > nsub / 2) want = nsub / 2;
+            while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > p.partial_bytes) --want;
+            (void)tiles;
+            S = want;
+        }
+    }
+#endif
     p.c8_S = S;
     p.pad = 1;
 #ifdef LD_AB_BUILD

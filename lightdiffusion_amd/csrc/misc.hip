@@ -245,28 +245,28 @@ __global__ __launch_bounds__(256) void timestep_embed_kernel(const float* sigma,
 }
 
 // ------------------------------------------------------------------------------------------------ CFG pair hand-over
-// each range's first half -> its second half, 16 bytes per lane and four of them in flight (one launch instead of one copy node per range)
+// each range's first half -> its second half, 16 bytes per lane and four of them in flight (one launch instead of one copy node per range).
+// Round 6: blockIdx.y = the range (no per-chunk range search), every load unconditional from a clamped index and only the stores predicated —
+// the first form put each of a thread's four loads behind its own branch (DESIGN "hipcc traps" (a): a wait per load) and took 30 us for
+// 8 MB as for 63 MB.
 __global__ __launch_bounds__(256) void dup_halves_kernel(const DupArgs a) {
-    const unsigned long long c0 = a.bytes[0] / 16, c1 = c0 + (a.count > 1 ? a.bytes[1] / 16 : 0), c2 = c1 + (a.count > 2 ? a.bytes[2] / 16 : 0);
-    const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < c2; q += 4 * step) {
+    const int r = blockIdx.y;
+    const char* src = r == 0 ? a.base[0] : (r == 1 ? a.base[1] : a.base[2]);
+    const unsigned long long nb = r == 0 ? a.bytes[0] : (r == 1 ? a.bytes[1] : a.bytes[2]);
+    const long long n = (long long)(nb / 16);
+    char* dst = const_cast<char*>(src) + nb;
+    for (long long q = (long long)blockIdx.x * 1024 + threadIdx.x; q < n; q += (long long)gridDim.x * 1024) {
         uint4 v[4];
-        char* dst[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const unsigned long long i = q + e * step;
-            dst[e] = nullptr;
-            if (i < c2) {
-                const int r = i < c0 ? 0 : (i < c1 ? 1 : 2);
-                const unsigned long long j = i - (r == 0 ? 0 : (r == 1 ? c0 : c1));
-                const char* src = a.base[r] + j * 16;
-                v[e] = *reinterpret_cast<const uint4*>(src);
-                dst[e] = a.base[r] + a.bytes[r] + j * 16;
-            }
+            const long long i = q + e * 256;
+            v[e] = *reinterpret_cast<const uint4*>(src + (i < n ? i : n - 1) * 16);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (dst[e] != nullptr) *reinterpret_cast<uint4*>(dst[e]) = v[e];
+        for (int e = 0; e < 4; ++e) {
+            const long long i = q + e * 256;
+            if (i < n) *reinterpret_cast<uint4*>(dst + i * 16) = v[e];
+        }
     }
 }
 
@@ -410,13 +410,13 @@ int timestep_embed_launch(const float* sigma, const float* log_sigmas, int n_sig
 
 int dup_halves_launch(const DupArgs& a, hipStream_t stream) {
     if (a.count < 1 || a.count > 3) return LD_ERR_ARG;
-    unsigned long long total = 0;
+    unsigned long long most = 0;
     for (int i = 0; i < a.count; ++i) {
-        if (a.base[i] == nullptr || (a.bytes[i] & 15) || (reinterpret_cast<uintptr_t>(a.base[i]) & 15)) return LD_ERR_ARG;
-        total += a.bytes[i] / 16;
+        if (a.base[i] == nullptr || a.bytes[i] == 0 || (a.bytes[i] & 15) || (reinterpret_cast<uintptr_t>(a.base[i]) & 15)) return LD_ERR_ARG;
+        if (a.bytes[i] / 16 > most) most = a.bytes[i] / 16;
     }
-    if (total == 0) return LD_OK;
-    hipLaunchKernelGGL(dup_halves_kernel, dim3(grid_for((long long)((total + 3) / 4), 256, 2048)), dim3(256), 0, stream, a);
+    // grid: x = 1024-chunk blocks of the longest range (shorter ranges' surplus blocks fall through the loop), y = the range
+    hipLaunchKernelGGL(dup_halves_kernel, dim3(grid_for((long long)most, 1024, 4096), a.count), dim3(256), 0, stream, a);
     return hipGetLastError() == hipSuccess ? LD_OK : LD_ERR_HIP;
 }
 
