@@ -2772,6 +2772,19 @@ static bool v6_plan(const GemmParams& p, V6Plan* out) {
         if (sk6 > NS) sk6 = NS;
         while (sk6 > 1 && (size_t)sk6 * p.M * p.N * sizeof(float) > p.partial_bytes) --sk6;
     }
+#ifdef LD_AB_BUILD
+    if (p.partial != nullptr && bn == V5_BN) {   // split-factor sweep of the halo convolution (tools/conv6_split_sweep.py): LD_V6_SK_W<width> = slices over K
+        static const char* names[4] = {"LD_V6_SK_W16", "LD_V6_SK_W32", "LD_V6_SK_W64", "LD_V6_SK_W128"};
+        const char* e = getenv(names[wc == 16 ? 0 : wc == 32 ? 1 : wc == 64 ? 2 : 3]);
+        if (e != nullptr) {
+            int want = atoi(e);
+            if (want < 1) want = 1;
+            if (want > NS) want = NS;
+            while (want > 1 && (size_t)want * p.M * p.N * sizeof(float) > p.partial_bytes) --want;
+            sk6 = want;
+        }
+    }
+#endif
     out->sk = sk6;
     out->bn = bn;
     out->bm = bm;
