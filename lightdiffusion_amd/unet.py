@@ -235,7 +235,8 @@ class MI355XUNet:
         same = self._ctx_ref is not None and self._ctx_ref.shape == c.shape and self._ctx_ref.dtype == c.dtype and torch.equal(c, self._ctx_ref)
         if not same:
             self.set_context(c)
-            self._ctx_ref = c.clone()
+            with torch.inference_mode(False):          # (a plain tensor: the wrapper hook may update it in place later, in either mode)
+                self._ctx_ref = c.clone()
         self._ctx_token = token
 
     def __call__(self, apply_model, params: dict) -> torch.Tensor:
