@@ -85,6 +85,23 @@ def test_attention_permutation_and_constant(ops, b, L, heads, d):
     assert (oc.float() - vc.float()).abs().max().item() < 4e-3
 
 
+@pytest.mark.parametrize("b,L", [(8, 4096), (2, 16384), (1, 3969)])
+def test_vae_attention_permutation_and_constant(ops, b, L):
+    """The VAE's single head of 512 channels (AttnBlock, LD.py:3591-3642; flash_attn512_kernel) at the sizes of the 512^2 and 1024^2 decodes and
+    at a ragged 63 x 63 latent: the same size-independent properties as the UNet's attention, through the fused [q | k | v] form the
+    executor hands over."""
+    c = 512
+    q, k, v = r16((b, L, c), 241), r16((b, L, c), 242), r16((b, L, c), 243)
+    o = ops.attention_qkv(torch.cat([q, k, v], -1).contiguous(), 1)
+    perm = torch.randperm(L, generator=torch.Generator().manual_seed(244)).to(DEV)
+    op = ops.attention_rowv(q, k[:, perm].contiguous(), v[:, perm].contiguous(), 1)
+    assert rel_l2(op.float().cpu(), o.float().cpu()) < 2e-3
+    vc = r16((b, 1, c), 245).expand(b, L, c).contiguous()
+    oc = ops.attention_rowv(q, k, vc, 1)
+    assert (oc.float() - vc.float()).abs().max().item() < 4e-3
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("n,hw,c", [(16, 4096, 320), (16, 1024, 1920), (8, 16384, 640)])
 def test_groupnorm_statistics_and_shift_invariance(ops, n, hw, c):
     """GroupNorm(32, eps 1e-5, affine) (LD.py:2391-2403): with gamma = 1, beta = 0 every (image, group) of the output has mean 0 and
